@@ -1,0 +1,288 @@
+/* rt_abi.h — C ABI of the MI355X render path (libracer_tracer_amd.so).
+ *
+ * This is the drop-in boundary for racer-tracer's renderer: everything the
+ * reference does between `Renderer::render` being called and the
+ * `ImageBufferEvent::BufferUpdate` tiles coming out
+ * (racer-tracer/src/renderer.rs:101-107, renderer/cpu.rs:26-131) happens
+ * behind the functions declared here.  The signatures use plain C types
+ * only (pointers, sizes, PODs) so that a Rust `impl Renderer` can bind them
+ * with `extern "C"` unchanged; INTEGRATION.md shows that binding.
+ *
+ * Every struct is a flattened ("described") form of a reference trait
+ * object; the comment on each one names the Rust type it replaces.
+ * All floating point is f64 like the reference (vec3.rs:13-16).
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+/* ------------------------------------------------------------------ errors
+ * 0 = Ok.  1..22 are exactly the reference's exit codes
+ * (racer-tracer/src/error.rs:71-97).  Codes >= 100 are new, GPU-side. */
+enum RtError {
+    RT_OK = 0,
+    RT_ERR_FAILED_TO_CREATE_WINDOW = 1,
+    RT_ERR_FAILED_TO_UPDATE_WINDOW = 2,
+    RT_ERR_CONFIGURATION = 3,
+    RT_ERR_UNKNOWN_MATERIAL = 4,
+    RT_ERR_FAILED_TO_ACQUIRE_LOCK = 5,
+    RT_ERR_EXIT_EVENT = 6,
+    RT_ERR_CANCEL_EVENT = 7,
+    RT_ERR_IMAGE_SAVE = 8,
+    RT_ERR_SCENE_LOAD = 9,
+    RT_ERR_ARGUMENT_PARSING = 10,
+    RT_ERR_KEY = 11,
+    RT_ERR_CREATE_LOG = 12,
+    RT_ERR_RECEIVE = 13,
+    RT_ERR_SEND = 14,
+    RT_ERR_ACTION_PROTOCOL = 15,
+    RT_ERR_BUS_WRITE = 16,
+    RT_ERR_BUS_READ = 17,
+    RT_ERR_BUS_UPDATE = 18,
+    RT_ERR_BUS_TIMEOUT = 19,
+    RT_ERR_NO_OBJECT_WITH_ID = 20,
+    RT_ERR_FAILED_TO_OPEN_IMAGE = 21,
+    RT_ERR_FAILED_TO_PARSE = 22,
+    /* new */
+    RT_ERR_NO_DEVICE = 100,      /* no HIP device / runtime unusable */
+    RT_ERR_HIP = 101,            /* a HIP call failed; see rt_last_error_message */
+    RT_ERR_INVALID_ARGUMENT = 102,
+    RT_ERR_UNSUPPORTED = 103,    /* scene uses something the device path lacks */
+    RT_ERR_OUT_OF_MEMORY = 104
+};
+
+/* ---------------------------------------------------------------- textures
+ * Flattened `dyn Texture` (texture.rs:8-10). */
+enum RtTextureKind {
+    RT_TEX_SOLID_COLOR = 0, /* texture/solid_color.rs:24-28  : color            */
+    RT_TEX_CHECKERED = 1,   /* texture/checkered.rs:32-42    : tex_even, tex_odd */
+    RT_TEX_IMAGE = 2,       /* texture/image.rs:28-51        : image            */
+    RT_TEX_NOISE = 3        /* texture/noise.rs:26-33        : color, scale, depth, perlin */
+};
+
+typedef struct RtTexture {
+    int32_t kind;
+    int32_t tex_even; /* Checkered: index of `texture_a` (used when sines >= 0) */
+    int32_t tex_odd;  /* Checkered: index of `texture_b` (used when sines <  0) */
+    int32_t image;    /* Image: index into RtSceneDesc.images                   */
+    int32_t perlin;   /* Noise: index into RtSceneDesc.perlins                  */
+    int32_t depth;    /* Noise: turbulence octaves                              */
+    double color[3];  /* SolidColor / Noise colour                              */
+    double scale;     /* Noise scale                                            */
+} RtTexture;
+
+/* Decoded image of a TextureImage: RGBA8, row-major, row 0 = top
+ * (what `image::open(..).into_rgba8()` yields, texture/image.rs:18-24). */
+typedef struct RtImage {
+    const uint8_t *rgba;
+    int32_t width;
+    int32_t height;
+} RtImage;
+
+/* One `Perlin` (texture/noise.rs:36-55): 256 unit gradient vectors and the
+ * three permutation tables (identity in the reference, noise.rs:121-130). */
+typedef struct RtPerlin {
+    double ranvec[256][3];
+    int32_t perm_x[256];
+    int32_t perm_y[256];
+    int32_t perm_z[256];
+} RtPerlin;
+
+/* --------------------------------------------------------------- materials
+ * Flattened `dyn Material` (material.rs:10-15). */
+enum RtMaterialKind {
+    RT_MAT_LAMBERTIAN = 0,   /* material/lambertian.rs:26-38   */
+    RT_MAT_METAL = 1,        /* material/metal.rs:26-43        */
+    RT_MAT_DIELECTRIC = 2,   /* material/dialectric.rs:25-55   */
+    RT_MAT_DIFFUSE_LIGHT = 3 /* material/diffuse_light.rs:25-37 */
+};
+
+typedef struct RtMaterial {
+    int32_t kind;
+    int32_t texture;         /* index into textures (unused for Dielectric) */
+    double fuzz;             /* Metal                                       */
+    double refraction_index; /* Dielectric                                  */
+} RtMaterial;
+
+/* --------------------------------------------------------------- primitives
+ * Flattened `SceneObject` + `dyn HittableSceneObject` (scene.rs:24-49).
+ * The YAML loader can wrap an object in at most one RotateY and then at
+ * most one Translate (scene/yml.rs:401-439), so the instance chain is two
+ * optional fields instead of a tree. */
+enum RtPrimitiveKind {
+    RT_PRIM_SPHERE = 0,  /* geometry/sphere.rs  : p = cx, cy, cz, radius        */
+    RT_PRIM_XY_RECT = 1, /* geometry/xy_rect.rs : p = x0, x1, y0, y1, k         */
+    RT_PRIM_XZ_RECT = 2, /* geometry/xz_rect.rs : p = x0, x1, z0, z1, k         */
+    RT_PRIM_YZ_RECT = 3, /* geometry/yz_rect.rs : p = y0, y1, z0, z1, k         */
+    RT_PRIM_BOX = 4      /* geometry/box.rs     : p = min xyz, max xyz          */
+};
+
+enum RtPrimitiveFlags {
+    RT_PRIM_HAS_ROTATE_Y = 1, /* geometry/rotate_y.rs, applied first (inner) */
+    RT_PRIM_HAS_TRANSLATE = 2 /* geometry/translate.rs, applied second (outer) */
+};
+
+typedef struct RtPrimitive {
+    int32_t kind;
+    int32_t material;
+    int32_t flags;
+    int32_t obj_id;      /* scene.rs:51,60 (informational; not read by the path) */
+    double p[6];
+    double rot_sin;      /* sin/cos of radians(degrees), rotate_y.rs:19-28 */
+    double rot_cos;
+    double translate[3]; /* translate.rs:13-16 */
+} RtPrimitive;
+
+/* -------------------------------------------------------------- background
+ * Flattened `dyn BackgroundColor` (background_color.rs:3-5). */
+enum RtBackgroundKind {
+    RT_BG_SKY = 0,  /* background_color.rs:27-33: (1-t)*top + t*bottom */
+    RT_BG_SOLID = 1 /* background_color.rs:45-48: `top` holds the colour */
+};
+
+typedef struct RtBackground {
+    int32_t kind;
+    int32_t _pad;
+    double top[3];
+    double bottom[3];
+} RtBackground;
+
+/* ------------------------------------------------------------------- scene
+ * `SceneLoadData.objects` + `.background` (scene.rs:109-114) in POD form.
+ * The library copies everything it needs in rt_scene_create; the caller
+ * may free the arrays afterwards. */
+typedef struct RtSceneDesc {
+    const RtPrimitive *primitives;
+    int32_t n_primitives;
+    const RtMaterial *materials;
+    int32_t n_materials;
+    const RtTexture *textures;
+    int32_t n_textures;
+    const RtImage *images;
+    int32_t n_images;
+    const RtPerlin *perlins;
+    int32_t n_perlins;
+    RtBackground background;
+} RtSceneDesc;
+
+/* ------------------------------------------------------------------ camera
+ * The 14 fields of `CameraSharedData` (camera.rs:56-72), passed per call
+ * because the camera changes between renders (main.rs:178-189). */
+typedef struct RtCamera {
+    double origin[3];
+    double upper_left_corner[3];
+    double forward[3];
+    double right[3];
+    double up[3];
+    double horizontal[3];
+    double vertical[3];
+    double vfov;
+    double viewport_width;
+    double viewport_height;
+    double lens_radius;
+    double focus_distance;
+    double time_a;
+    double time_b;
+} RtCamera;
+
+/* ------------------------------------------------------------------ params
+ * `Image` (image.rs:3-8) + `RenderConfig` (config.rs:75-82) + the seed the
+ * reference does not have (util.rs:9-23 is OS-seeded). */
+typedef struct RtRenderParams {
+    int32_t width;      /* screen.width  */
+    int32_t height;     /* screen.height */
+    int32_t samples;    /* render.samples   */
+    int32_t max_depth;  /* render.max_depth */
+    int32_t tiles_w;    /* render.num_threads_width  (tile grid of rt_render) */
+    int32_t tiles_h;    /* render.num_threads_height */
+    uint64_t seed;      /* key of the counter-based RNG (rt_rng.h) */
+    /* Row ownership for multi-GPU renders: this call renders the image rows
+     * r with (r / strip_rows) % strip_count == strip_index and leaves the
+     * others untouched.  strip_count <= 1 means "all rows". */
+    int32_t strip_rows;
+    int32_t strip_count;
+    int32_t strip_index;
+    int32_t _pad;
+} RtRenderParams;
+
+typedef struct RtScene RtScene; /* opaque; owned by the library */
+
+/* Statistics of the last render on a scene (path segments = ray_color
+ * levels actually evaluated; feeds the roofline figure of bench.py). */
+typedef struct RtRenderStats {
+    uint64_t samples;        /* primary rays traced               */
+    uint64_t segments;       /* sum over samples of path length   */
+    double kernel_ms;        /* HIP-event time of the trace kernel(s), this call */
+    double resolve_ms;       /* HIP-event time of the resolve kernel, this call  */
+    int32_t kernel_launches; /* trace-kernel launches in this call */
+    int32_t _pad;
+} RtRenderStats;
+
+/* Tile callback = one `ImageBufferEvent::BufferUpdate{rgb,r,c,width,height}`
+ * (image_buffer.rs:62-71): `rgb` is width*height*3 f64, row-major, already
+ * divided by samples and sqrt'd, NOT tone-mapped (cpu.rs:52,64-70).
+ * `rgb` is only valid during the call. */
+typedef void (*RtTileCallback)(void *user, const double *rgb, int32_t r, int32_t c,
+                               int32_t width, int32_t height);
+
+/* --------------------------------------------------------------- functions */
+
+/* ABI version of the loaded library (== RT_ABI_VERSION of its build). */
+int rt_abi_version(void);
+
+/* Number of usable HIP devices (0 when there is none or the runtime is
+ * unusable).  Never fails. */
+int rt_device_count(void);
+
+/* Upload a scene to a device.  Replaces handing `&dyn Hittable` +
+ * `&dyn BackgroundColor` to the renderer (renderer.rs:92-99); re-doable
+ * because the reference rebuilds its BVH between renders (main.rs:178). */
+int rt_scene_create(const RtSceneDesc *desc, int device, RtScene **out);
+void rt_scene_destroy(RtScene *scene);
+
+/* Replaces `CpuRenderer::render` (renderer/cpu.rs:118-131) with the whole
+ * frame as ONE BufferUpdate (legal: renderer/image.rs:56-62 does the same).
+ * out_rgb: caller-owned HOST memory, width*height*3 f64, row-major, row 0 =
+ * top; gamma-encoded (sqrt(sum/samples)), not tone-mapped, not clamped. */
+int rt_render_frame(RtScene *scene, const RtCamera *camera, const RtRenderParams *params,
+                    double *out_rgb);
+
+/* Same, but out_rgb_device is DEVICE memory of the scene's device and the
+ * work is enqueued on `hip_stream` (a hipStream_t; NULL = default stream)
+ * without synchronising: the caller (or a collective on the same stream)
+ * orders against it.  Rows not owned under params->strip_* are not written. */
+int rt_render_frame_device(RtScene *scene, const RtCamera *camera,
+                           const RtRenderParams *params, double *out_rgb_device,
+                           void *hip_stream);
+
+/* Replaces `CpuRenderer::render` with the reference's own tile stream:
+ * tiles_w x tiles_h tiles in column-major order with the last row/column
+ * absorbing remainders (cpu.rs:73-115), one callback per tile.  `cancel`
+ * (may be NULL) is polled like `do_cancel` (renderer.rs:25-30): when it
+ * becomes non-zero the call returns RT_OK without emitting further tiles
+ * (cpu.rs:55-62). */
+int rt_render(RtScene *scene, const RtCamera *camera, const RtRenderParams *params,
+              RtTileCallback callback, void *user, const volatile int *cancel);
+
+/* Stats of the most recent render call on this scene (synchronises the
+ * stream of that call first). */
+int rt_scene_last_stats(RtScene *scene, RtRenderStats *out);
+
+/* Static description of an error code; never NULL. */
+const char *rt_strerror(int code);
+/* Thread-local detail of the last failure in this library ("" if none). */
+const char *rt_last_error_message(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RT_ABI_H */

@@ -1,0 +1,111 @@
+"""racer-tracer_amd — ctypes binding of libracer_tracer_amd.so (MI355X / gfx950).
+
+The package name contains a hyphen like the reference crate's, so import it
+with ``importlib.import_module("racer-tracer_amd")``.
+
+This is plumbing over the C ABI of include/rt_abi.h (device path) and
+include/rt_host.h (scene/config loading, tone map, PNG).  There is NO CPU
+fallback: if the shared library is missing or no GPU is visible, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libracer_tracer_amd.so")
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, what, detail):
+        super().__init__("%s failed: [%d] %s%s" % (what, code, _strerror(code), (": " + detail) if detail else ""))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library (raises if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: build it with `make -C %s` (or __graft_entry__.build()); "
+                "there is no CPU fallback for the render path" % (LIB_PATH, _HERE))
+        _lib = abi.bind(C.CDLL(LIB_PATH), abi.PROTOTYPES)
+        if _lib.rt_abi_version() != abi.ABI_VERSION:
+            raise ImportError("ABI version mismatch: library %d, binding %d"
+                              % (_lib.rt_abi_version(), abi.ABI_VERSION))
+    return _lib
+
+
+def _strerror(code):
+    try:
+        return lib().rt_strerror(code).decode()
+    except Exception:  # pragma: no cover - only when the library itself is missing
+        return "?"
+
+
+def check(code, what):
+    if code != abi.RT_OK:
+        raise RtError(code, what, lib().rt_last_error_message().decode())
+
+
+def device_count():
+    return lib().rt_device_count()
+
+
+class Scene:
+    """RtScene handle: a scene uploaded to one GPU (rt_scene_create)."""
+
+    def __init__(self, desc, device=0):
+        self._h = C.c_void_p()
+        self._desc_owner = desc  # keep SceneBundle / host session alive
+        d = desc.desc if hasattr(desc, "desc") else desc
+        check(lib().rt_scene_create(C.byref(d), device, C.byref(self._h)), "rt_scene_create")
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().rt_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render_frame(self, camera, params):
+        """rt_render_frame -> float64 [H, W, 3], gamma-encoded, not tone-mapped."""
+        out = np.zeros((params.height, params.width, 3), dtype=np.float64)
+        check(lib().rt_render_frame(self._h, C.byref(camera), C.byref(params),
+                                    out.ctypes.data_as(C.POINTER(C.c_double))), "rt_render_frame")
+        return out
+
+    def render_frame_device(self, camera, params, out_ptr, stream=None):
+        """rt_render_frame_device: out_ptr = device address (int), stream = hipStream_t (int)."""
+        check(lib().rt_render_frame_device(self._h, C.byref(camera), C.byref(params),
+                                           C.c_void_p(out_ptr), C.c_void_p(stream or 0)),
+              "rt_render_frame_device")
+
+    def render_tiles(self, camera, params, cancel=None):
+        """rt_render -> list of (r, c, width, height, float64 [height, width, 3])."""
+        tiles = []
+
+        def on_tile(_user, rgb, r, c, w, h):
+            arr = np.ctypeslib.as_array(rgb, shape=(h, w, 3)).copy()
+            tiles.append((r, c, w, h, arr))
+
+        cb = abi.RtTileCallback(on_tile)
+        cancel_ptr = C.cast(cancel, C.POINTER(C.c_int)) if cancel is not None else None
+        check(lib().rt_render(self._h, C.byref(camera), C.byref(params), cb, None, cancel_ptr), "rt_render")
+        return tiles
+
+    def last_stats(self):
+        st = abi.RtRenderStats()
+        check(lib().rt_scene_last_stats(self._h, C.byref(st)), "rt_scene_last_stats")
+        return st

@@ -1,0 +1,518 @@
+// rt_api.hip — implementation of the C ABI declared in include/rt_abi.h.
+//
+// Host code only (HIP runtime calls); the kernels live in
+// rt_trace_kernel.hip.  Nothing here falls back to a CPU renderer: without a
+// usable HIP device every entry point returns RT_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+#include <string>
+#include <vector>
+#include "rt_device_types.h"
+#include "../../include/rt_abi.h"
+
+extern "C" hipError_t rtdev_launch_trace(const rtdev::TraceArgs *args, int prims_class, int textured,
+                                         int specular, hipStream_t stream);
+extern "C" hipError_t rtdev_launch_resolve(const double *accum, double *out, int width, int height,
+                                           int strip_rows, int strip_count, int strip_index, int samples,
+                                           hipStream_t stream);
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define RT_HIP(call)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(RT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+template <class T> struct DevBuf {
+    T *ptr = nullptr;
+    size_t count = 0;
+    hipError_t alloc(size_t n) {
+        release();
+        if (n == 0) return hipSuccess;
+        hipError_t e = hipMalloc((void **)&ptr, n * sizeof(T));
+        if (e == hipSuccess) count = n;
+        return e;
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        count = 0;
+    }
+};
+
+} // namespace
+
+struct RtScene {
+    int device = 0;
+    DevBuf<rtdev::Prim> prims;
+    DevBuf<rtdev::Material> materials;
+    DevBuf<rtdev::Texture> textures;
+    DevBuf<rtdev::Image> images;
+    DevBuf<rtdev::Perlin> perlins;
+    std::vector<uint8_t *> image_pixels; // device copies of the RGBA8 texels
+    int n_prims = 0, n_materials = 0, n_textures = 0, n_images = 0, n_perlins = 0;
+    rtdev::Background bg;
+    // kernel specialisation (rt_trace_kernel.hip): 0 rects only, 1 spheres only, 2 anything
+    int prims_class = 2;
+    int textured = 0; // some material's texture is not a plain SolidColor
+    int specular = 0; // some material is Metal or Dielectric
+
+    DevBuf<double> accum;  // running sums, W*H*3
+    DevBuf<double> frame;  // resolved frame for the host-output entry points
+    DevBuf<unsigned long long> segments;
+    hipStream_t stream = nullptr; // used by rt_render_frame / rt_render
+    hipEvent_t ev_begin = nullptr, ev_traced = nullptr, ev_resolved = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool has_stats = false;
+    uint64_t last_samples = 0;
+    int last_launches = 0;
+};
+
+namespace {
+
+int validate_desc(const RtSceneDesc *d) {
+    if (!d) return fail(RT_ERR_INVALID_ARGUMENT, "scene description is NULL");
+    if (d->n_primitives < 0 || d->n_materials < 0 || d->n_textures < 0 || d->n_images < 0 || d->n_perlins < 0)
+        return fail(RT_ERR_INVALID_ARGUMENT, "negative table size");
+    if ((d->n_primitives && !d->primitives) || (d->n_materials && !d->materials) ||
+        (d->n_textures && !d->textures) || (d->n_images && !d->images) || (d->n_perlins && !d->perlins))
+        return fail(RT_ERR_INVALID_ARGUMENT, "NULL table with non-zero size");
+    for (int i = 0; i < d->n_textures; ++i) {
+        const RtTexture &t = d->textures[i];
+        switch (t.kind) {
+        case RT_TEX_SOLID_COLOR: break;
+        case RT_TEX_CHECKERED:
+            for (int c : {t.tex_even, t.tex_odd}) {
+                if (c < 0 || c >= d->n_textures)
+                    return fail(RT_ERR_SCENE_LOAD, "Checkered texture " + std::to_string(i) + " names a missing texture");
+                if (d->textures[c].kind == RT_TEX_CHECKERED) // scene/yml.rs:212-243 resolves one level only
+                    return fail(RT_ERR_UNSUPPORTED, "Checkered texture of a Checkered texture");
+            }
+            break;
+        case RT_TEX_IMAGE:
+            if (t.image < 0 || t.image >= d->n_images) return fail(RT_ERR_INVALID_ARGUMENT, "texture image index out of range");
+            break;
+        case RT_TEX_NOISE:
+            if (t.perlin < 0 || t.perlin >= d->n_perlins) return fail(RT_ERR_INVALID_ARGUMENT, "texture perlin index out of range");
+            if (t.depth < 0) return fail(RT_ERR_INVALID_ARGUMENT, "negative noise depth");
+            break;
+        default: return fail(RT_ERR_INVALID_ARGUMENT, "unknown texture kind");
+        }
+    }
+    for (int i = 0; i < d->n_images; ++i)
+        if (!d->images[i].rgba || d->images[i].width <= 0 || d->images[i].height <= 0)
+            return fail(RT_ERR_FAILED_TO_OPEN_IMAGE, "image " + std::to_string(i) + " is empty");
+    for (int i = 0; i < d->n_materials; ++i) {
+        const RtMaterial &m = d->materials[i];
+        if (m.kind < RT_MAT_LAMBERTIAN || m.kind > RT_MAT_DIFFUSE_LIGHT)
+            return fail(RT_ERR_UNKNOWN_MATERIAL, "unknown material kind");
+        if (m.kind != RT_MAT_DIELECTRIC && (m.texture < 0 || m.texture >= d->n_textures))
+            return fail(RT_ERR_SCENE_LOAD, "material " + std::to_string(i) + " names a missing texture");
+    }
+    for (int i = 0; i < d->n_primitives; ++i) {
+        const RtPrimitive &p = d->primitives[i];
+        if (p.kind < RT_PRIM_SPHERE || p.kind > RT_PRIM_BOX) return fail(RT_ERR_INVALID_ARGUMENT, "unknown primitive kind");
+        if (p.material < 0 || p.material >= d->n_materials)
+            return fail(RT_ERR_UNKNOWN_MATERIAL, "primitive " + std::to_string(i) + " names a missing material");
+    }
+    if (d->background.kind != RT_BG_SKY && d->background.kind != RT_BG_SOLID)
+        return fail(RT_ERR_INVALID_ARGUMENT, "unknown background kind");
+    return RT_OK;
+}
+
+bool texture_reads_uv(const RtSceneDesc *d, int ti) {
+    const RtTexture &t = d->textures[ti];
+    if (t.kind == RT_TEX_IMAGE) return true;
+    if (t.kind == RT_TEX_CHECKERED)
+        return d->textures[t.tex_even].kind == RT_TEX_IMAGE || d->textures[t.tex_odd].kind == RT_TEX_IMAGE;
+    return false;
+}
+
+template <class T> int upload(DevBuf<T> &buf, const std::vector<T> &host) {
+    RT_HIP(buf.alloc(host.size()));
+    if (!host.empty()) RT_HIP(hipMemcpy(buf.ptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+int check_params(const RtCamera *camera, const RtRenderParams *p) {
+    if (!camera || !p) return fail(RT_ERR_INVALID_ARGUMENT, "camera/params is NULL");
+    if (p->width <= 0 || p->height <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "width and height must be positive");
+    if (p->samples <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "samples must be positive");
+    if (p->max_depth < 0 || p->max_depth >= (1 << 24)) return fail(RT_ERR_INVALID_ARGUMENT, "max_depth out of range");
+    if ((uint64_t)p->width * (uint64_t)p->height > 0xFFFFFFFFull) return fail(RT_ERR_INVALID_ARGUMENT, "image too large for the pixel counter");
+    if (p->strip_count > 1) {
+        if (p->strip_rows <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "strip_rows must be positive when strip_count > 1");
+        if (p->strip_index < 0 || p->strip_index >= p->strip_count) return fail(RT_ERR_INVALID_ARGUMENT, "strip_index out of range");
+    }
+    return RT_OK;
+}
+
+void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtdev::TraceArgs &a) {
+    memset(&a, 0, sizeof a);
+    a.prims = s->prims.ptr;
+    a.materials = s->materials.ptr;
+    a.textures = s->textures.ptr;
+    a.images = s->images.ptr;
+    a.perlins = s->perlins.ptr;
+    a.n_prims = s->n_prims;
+    a.n_materials = s->n_materials;
+    a.n_textures = s->n_textures;
+    a.n_images = s->n_images;
+    a.n_perlins = s->n_perlins;
+    a.width = p->width;
+    a.height = p->height;
+    a.samples = p->samples;
+    a.max_depth = p->max_depth;
+    a.sample_begin = 0;
+    a.sample_end = p->samples;
+    if (p->strip_count > 1) {
+        a.strip_rows = p->strip_rows;
+        a.strip_count = p->strip_count;
+        a.strip_index = p->strip_index;
+        int owned_strips = 0; // strips j with first row (j*count + index)*rows inside the image
+        for (long long j = 0; (j * p->strip_count + p->strip_index) * (long long)p->strip_rows < p->height; ++j) ++owned_strips;
+        a.owned_rows = owned_strips * p->strip_rows;
+    } else {
+        a.strip_rows = p->height;
+        a.strip_count = 1;
+        a.strip_index = 0;
+        a.owned_rows = p->height;
+    }
+    a.seed_lo = (uint32_t)(p->seed & 0xffffffffull);
+    a.seed_hi = (uint32_t)(p->seed >> 32);
+    for (int k = 0; k < 3; ++k) {
+        a.cam.origin[k] = c->origin[k];
+        a.cam.ulc[k] = c->upper_left_corner[k];
+        a.cam.right[k] = c->right[k];
+        a.cam.up[k] = c->up[k];
+        a.cam.horizontal[k] = c->horizontal[k];
+        a.cam.vertical[k] = c->vertical[k];
+    }
+    a.cam.lens_radius = c->lens_radius;
+    a.bg = s->bg;
+    a.accum = s->accum.ptr;
+    a.segments = s->segments.ptr;
+}
+
+// Enqueue trace (in sample batches, polling `cancel` between them) + resolve.
+// Returns RT_ERR_CANCEL_EVENT when cancelled (callers map that to RT_OK).
+int enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, double *out_device,
+                   hipStream_t stream, int batch, const volatile int *cancel) {
+    RT_HIP(hipSetDevice(s->device));
+    size_t n = (size_t)p->width * (size_t)p->height * 3;
+    if (s->accum.count < n) RT_HIP(s->accum.alloc(n));
+    rtdev::TraceArgs a;
+    fill_args(s, camera, p, a);
+    RT_HIP(hipMemsetAsync(s->segments.ptr, 0, sizeof(unsigned long long), stream));
+    RT_HIP(hipEventRecord(s->ev_begin, stream));
+    int launches = 0;
+    if (batch <= 0 || batch > p->samples) batch = p->samples;
+    for (int b = 0; b < p->samples; b += batch) {
+        if (cancel && *cancel) return RT_ERR_CANCEL_EVENT;
+        a.sample_begin = b;
+        a.sample_end = b + batch < p->samples ? b + batch : p->samples;
+        RT_HIP(rtdev_launch_trace(&a, s->prims_class, s->textured, s->specular, stream));
+        ++launches;
+        if (cancel) RT_HIP(hipStreamSynchronize(stream)); // so the next poll is meaningful
+    }
+    RT_HIP(hipEventRecord(s->ev_traced, stream));
+    RT_HIP(rtdev_launch_resolve(s->accum.ptr, out_device, p->width, p->height, a.strip_rows, a.strip_count,
+                                a.strip_index, p->samples, stream));
+    RT_HIP(hipEventRecord(s->ev_resolved, stream));
+    s->last_stream = stream;
+    s->has_stats = true;
+    s->last_launches = launches;
+    // primary rays traced = owned pixels x samples
+    uint64_t owned = 0;
+    for (int r = 0; r < p->height; ++r)
+        if (a.strip_count <= 1 || (r / a.strip_rows) % a.strip_count == a.strip_index) ++owned;
+    s->last_samples = owned * (uint64_t)p->width * (uint64_t)p->samples;
+    return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *rt_last_error_message(void) { return g_last_error.c_str(); }
+
+const char *rt_strerror(int code) {
+    switch (code) {
+    case RT_OK: return "Ok";
+    case RT_ERR_FAILED_TO_CREATE_WINDOW: return "Failed to create window";
+    case RT_ERR_FAILED_TO_UPDATE_WINDOW: return "Failed to update window";
+    case RT_ERR_CONFIGURATION: return "Config Error";
+    case RT_ERR_UNKNOWN_MATERIAL: return "Unknown Material";
+    case RT_ERR_FAILED_TO_ACQUIRE_LOCK: return "Failed to acquire lock";
+    case RT_ERR_EXIT_EVENT: return "Exit event";
+    case RT_ERR_CANCEL_EVENT: return "Cancel event";
+    case RT_ERR_IMAGE_SAVE: return "Image save error";
+    case RT_ERR_SCENE_LOAD: return "Scene failed to load";
+    case RT_ERR_ARGUMENT_PARSING: return "Argument parsing Error";
+    case RT_ERR_KEY: return "Key callback failed";
+    case RT_ERR_CREATE_LOG: return "Failed to create log";
+    case RT_ERR_RECEIVE: return "Failed to recieve data";
+    case RT_ERR_SEND: return "Failed to send data";
+    case RT_ERR_ACTION_PROTOCOL: return "Action protocol error";
+    case RT_ERR_BUS_WRITE: return "Failed to write data to bus";
+    case RT_ERR_BUS_READ: return "Failed to read data from bus";
+    case RT_ERR_BUS_UPDATE: return "Failed to update databus";
+    case RT_ERR_BUS_TIMEOUT: return "Bus timeout error";
+    case RT_ERR_NO_OBJECT_WITH_ID: return "No object with id";
+    case RT_ERR_FAILED_TO_OPEN_IMAGE: return "Failed to open image";
+    case RT_ERR_FAILED_TO_PARSE: return "Failed to parse into a vector";
+    case RT_ERR_NO_DEVICE: return "No usable HIP device";
+    case RT_ERR_HIP: return "HIP runtime error";
+    case RT_ERR_INVALID_ARGUMENT: return "Invalid argument";
+    case RT_ERR_UNSUPPORTED: return "Unsupported scene feature";
+    case RT_ERR_OUT_OF_MEMORY: return "Out of memory";
+    default: return "Unknown error";
+    }
+}
+
+void rt_scene_destroy(RtScene *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (uint8_t *p : s->image_pixels)
+        if (p) (void)hipFree(p);
+    s->prims.release();
+    s->materials.release();
+    s->textures.release();
+    s->images.release();
+    s->perlins.release();
+    s->accum.release();
+    s->frame.release();
+    s->segments.release();
+    if (s->ev_begin) (void)hipEventDestroy(s->ev_begin);
+    if (s->ev_traced) (void)hipEventDestroy(s->ev_traced);
+    if (s->ev_resolved) (void)hipEventDestroy(s->ev_resolved);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
+    if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    int rc = validate_desc(d);
+    if (rc != RT_OK) return rc;
+    int n_dev = rt_device_count();
+    if (n_dev <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device is visible to this process");
+    if (device < 0 || device >= n_dev) return fail(RT_ERR_INVALID_ARGUMENT, "device index out of range");
+    RT_HIP(hipSetDevice(device));
+
+    RtScene *s = new (std::nothrow) RtScene();
+    if (!s) return fail(RT_ERR_OUT_OF_MEMORY, "host allocation failed");
+    s->device = device;
+    struct Guard { // destroy the half-built scene on any early return
+        RtScene *s;
+        ~Guard() { if (s) rt_scene_destroy(s); }
+    } guard{s};
+
+    std::vector<rtdev::Prim> prims((size_t)d->n_primitives);
+    for (int i = 0; i < d->n_primitives; ++i) {
+        const RtPrimitive &p = d->primitives[i];
+        rtdev::Prim &q = prims[(size_t)i];
+        memset(&q, 0, sizeof q);
+        for (int k = 0; k < 6; ++k) q.p[k] = p.p[k];
+        q.rot_sin = p.rot_sin;
+        q.rot_cos = p.rot_cos;
+        for (int k = 0; k < 3; ++k) q.tr[k] = p.translate[k];
+        q.kind = p.kind;
+        q.flags = p.flags & (RT_PRIM_HAS_ROTATE_Y | RT_PRIM_HAS_TRANSLATE);
+        q.material = p.material;
+        q.inv_radius = p.kind == RT_PRIM_SPHERE ? 1.0 / p.p[3] : 0.0;
+    }
+    std::vector<rtdev::Texture> textures((size_t)d->n_textures);
+    for (int i = 0; i < d->n_textures; ++i) {
+        const RtTexture &t = d->textures[i];
+        rtdev::Texture &q = textures[(size_t)i];
+        memset(&q, 0, sizeof q);
+        q.kind = t.kind;
+        q.tex_even = t.tex_even;
+        q.tex_odd = t.tex_odd;
+        q.image = t.image;
+        q.perlin = t.perlin;
+        q.depth = t.depth;
+        for (int k = 0; k < 3; ++k) q.color[k] = t.color[k];
+        q.scale = t.scale;
+    }
+    std::vector<rtdev::Material> materials((size_t)d->n_materials);
+    for (int i = 0; i < d->n_materials; ++i) {
+        const RtMaterial &m = d->materials[i];
+        rtdev::Material &q = materials[(size_t)i];
+        memset(&q, 0, sizeof q);
+        q.kind = m.kind;
+        q.texture = m.texture;
+        q.tex_kind = -1;
+        q.fuzz = m.fuzz;
+        q.ior = m.refraction_index;
+        if (m.kind != RT_MAT_DIELECTRIC) {
+            const RtTexture &t = d->textures[m.texture];
+            q.tex_kind = t.kind;
+            q.needs_uv = texture_reads_uv(d, m.texture) ? 1 : 0;
+            for (int k = 0; k < 3; ++k) q.color[k] = t.color[k];
+        }
+    }
+    std::vector<rtdev::Image> images((size_t)d->n_images);
+    s->image_pixels.assign((size_t)d->n_images, nullptr);
+    for (int i = 0; i < d->n_images; ++i) {
+        size_t bytes = (size_t)d->images[i].width * (size_t)d->images[i].height * 4;
+        RT_HIP(hipMalloc((void **)&s->image_pixels[(size_t)i], bytes));
+        RT_HIP(hipMemcpy(s->image_pixels[(size_t)i], d->images[i].rgba, bytes, hipMemcpyHostToDevice));
+        images[(size_t)i].rgba = s->image_pixels[(size_t)i];
+        images[(size_t)i].width = d->images[i].width;
+        images[(size_t)i].height = d->images[i].height;
+    }
+    std::vector<rtdev::Perlin> perlins((size_t)d->n_perlins);
+    for (int i = 0; i < d->n_perlins; ++i) {
+        static_assert(sizeof(rtdev::Perlin) == sizeof(RtPerlin), "Perlin layouts must match");
+        memcpy(&perlins[(size_t)i], &d->perlins[i], sizeof(RtPerlin));
+    }
+    bool only_rects = true, only_spheres = true;
+    for (const rtdev::Prim &q : prims) {
+        bool is_rect = q.kind == RT_PRIM_XY_RECT || q.kind == RT_PRIM_XZ_RECT || q.kind == RT_PRIM_YZ_RECT;
+        if (q.flags || !is_rect) only_rects = false;
+        if (q.flags || q.kind != RT_PRIM_SPHERE) only_spheres = false;
+    }
+    s->prims_class = only_rects ? 0 : (only_spheres ? 1 : 2);
+    for (const rtdev::Material &q : materials) {
+        if (q.kind == RT_MAT_METAL || q.kind == RT_MAT_DIELECTRIC) s->specular = 1;
+        if (q.kind != RT_MAT_DIELECTRIC && q.tex_kind != RT_TEX_SOLID_COLOR) s->textured = 1;
+    }
+    if ((rc = upload(s->prims, prims)) != RT_OK) return rc;
+    if ((rc = upload(s->textures, textures)) != RT_OK) return rc;
+    if ((rc = upload(s->materials, materials)) != RT_OK) return rc;
+    if ((rc = upload(s->images, images)) != RT_OK) return rc;
+    if ((rc = upload(s->perlins, perlins)) != RT_OK) return rc;
+    s->n_prims = d->n_primitives;
+    s->n_materials = d->n_materials;
+    s->n_textures = d->n_textures;
+    s->n_images = d->n_images;
+    s->n_perlins = d->n_perlins;
+    s->bg.kind = d->background.kind;
+    for (int k = 0; k < 3; ++k) {
+        s->bg.top[k] = d->background.top[k];
+        s->bg.bottom[k] = d->background.bottom[k];
+    }
+    RT_HIP(s->segments.alloc(1));
+    RT_HIP(hipMemset(s->segments.ptr, 0, sizeof(unsigned long long)));
+    RT_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    RT_HIP(hipEventCreate(&s->ev_begin));
+    RT_HIP(hipEventCreate(&s->ev_traced));
+    RT_HIP(hipEventCreate(&s->ev_resolved));
+    guard.s = nullptr;
+    *out = s;
+    return RT_OK;
+}
+
+int rt_render_frame_device(RtScene *s, const RtCamera *camera, const RtRenderParams *p, double *out_dev,
+                           void *hip_stream) {
+    if (!s || !out_dev) return fail(RT_ERR_INVALID_ARGUMENT, "scene/out is NULL");
+    int rc = check_params(camera, p);
+    if (rc != RT_OK) return rc;
+    return enqueue_render(s, camera, p, out_dev, (hipStream_t)hip_stream, 0, nullptr);
+}
+
+int rt_render_frame(RtScene *s, const RtCamera *camera, const RtRenderParams *p, double *out_rgb) {
+    if (!s || !out_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "scene/out is NULL");
+    int rc = check_params(camera, p);
+    if (rc != RT_OK) return rc;
+    RT_HIP(hipSetDevice(s->device));
+    size_t n = (size_t)p->width * (size_t)p->height * 3;
+    if (s->frame.count < n) RT_HIP(s->frame.alloc(n));
+    rc = enqueue_render(s, camera, p, s->frame.ptr, s->stream, 0, nullptr);
+    if (rc != RT_OK) return rc;
+    RT_HIP(hipStreamSynchronize(s->stream));
+    if (p->strip_count > 1) { // copy the owned rows only; the rest of out_rgb stays untouched
+        size_t row_bytes = (size_t)p->width * 3 * sizeof(double);
+        for (int r = 0; r < p->height; ++r)
+            if ((r / p->strip_rows) % p->strip_count == p->strip_index)
+                RT_HIP(hipMemcpy(out_rgb + (size_t)r * p->width * 3, s->frame.ptr + (size_t)r * p->width * 3,
+                                 row_bytes, hipMemcpyDeviceToHost));
+    } else {
+        RT_HIP(hipMemcpy(out_rgb, s->frame.ptr, n * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return RT_OK;
+}
+
+int rt_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, RtTileCallback callback, void *user,
+              const volatile int *cancel) {
+    if (!s || !callback) return fail(RT_ERR_INVALID_ARGUMENT, "scene/callback is NULL");
+    int rc = check_params(camera, p);
+    if (rc != RT_OK) return rc;
+    if (p->tiles_w <= 0 || p->tiles_h <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "tile grid must be positive");
+    if (cancel && *cancel) return RT_ERR_CANCEL_EVENT; // cpu.rs:82-85: prepare_threads fails with CancelEvent
+    RT_HIP(hipSetDevice(s->device));
+    size_t n = (size_t)p->width * (size_t)p->height * 3;
+    if (s->frame.count < n) RT_HIP(s->frame.alloc(n));
+    // with a cancel flag, trace in batches so the flag is polled about as often
+    // as the reference polls it per tile row (cpu.rs:55)
+    int batch = cancel ? (p->samples > 16 ? 16 : p->samples) : 0;
+    rc = enqueue_render(s, camera, p, s->frame.ptr, s->stream, batch, cancel);
+    if (rc == RT_ERR_CANCEL_EVENT) { // cpu.rs:55-62: return Ok, no tile written
+        (void)hipStreamSynchronize(s->stream);
+        return RT_OK;
+    }
+    if (rc != RT_OK) return rc;
+    RT_HIP(hipStreamSynchronize(s->stream));
+    std::vector<double> frame(n);
+    RT_HIP(hipMemcpy(frame.data(), s->frame.ptr, n * sizeof(double), hipMemcpyDeviceToHost));
+    // cpu.rs:73-115 tile grid, column-major, remainders in the last row/column
+    int width_step = p->width / p->tiles_w, height_step = p->height / p->tiles_h;
+    std::vector<double> tile;
+    for (int ws = 0; ws < p->tiles_w; ++ws)
+        for (int hs = 0; hs < p->tiles_h; ++hs) {
+            if (cancel && *cancel) return RT_OK;
+            int x = width_step * ws, y = height_step * hs;
+            int w = ws == p->tiles_w - 1 ? p->width - x : width_step;
+            int h = hs == p->tiles_h - 1 ? p->height - y : height_step;
+            if (w <= 0 || h <= 0) continue;
+            tile.resize((size_t)w * (size_t)h * 3);
+            for (int r = 0; r < h; ++r)
+                memcpy(&tile[(size_t)r * w * 3], &frame[((size_t)(y + r) * p->width + x) * 3], (size_t)w * 3 * sizeof(double));
+            callback(user, tile.data(), y, x, w, h);
+        }
+    return RT_OK;
+}
+
+int rt_scene_last_stats(RtScene *s, RtRenderStats *out) {
+    if (!s || !out) return fail(RT_ERR_INVALID_ARGUMENT, "scene/out is NULL");
+    memset(out, 0, sizeof *out);
+    if (!s->has_stats) return RT_OK;
+    RT_HIP(hipSetDevice(s->device));
+    RT_HIP(hipEventSynchronize(s->ev_resolved));
+    float ms_trace = 0.f, ms_resolve = 0.f;
+    RT_HIP(hipEventElapsedTime(&ms_trace, s->ev_begin, s->ev_traced));
+    RT_HIP(hipEventElapsedTime(&ms_resolve, s->ev_traced, s->ev_resolved));
+    unsigned long long segs = 0;
+    RT_HIP(hipMemcpy(&segs, s->segments.ptr, sizeof segs, hipMemcpyDeviceToHost));
+    out->samples = s->last_samples;
+    out->segments = segs;
+    out->kernel_ms = ms_trace;
+    out->resolve_ms = ms_resolve;
+    out->kernel_launches = s->last_launches;
+    return RT_OK;
+}
+
+} // extern "C"

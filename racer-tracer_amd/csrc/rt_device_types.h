@@ -1,0 +1,89 @@
+// rt_device_types.h — device-side tables of a scene, as laid out in HBM.
+//
+// These are the upload forms of include/rt_abi.h's PODs: same content,
+// re-packed so that (a) the closest-hit loop reads one 128-byte record per
+// primitive with a wave-uniform index (scalar loads) and (b) what shading
+// needs about a material — kind, fuzz, ior, and the colour when its texture
+// is a plain SolidColor — sits in one record, so the common case costs a
+// single per-lane gather.
+#pragma once
+#include <stdint.h>
+
+namespace rtdev {
+
+struct alignas(16) Prim { // 128 B
+    double p[6];          // sphere: c.xyz, r | rect: a0,a1,b0,b1,k | box: min.xyz,max.xyz
+    double rot_sin, rot_cos;
+    double tr[3];
+    int32_t kind;         // RtPrimitiveKind
+    int32_t flags;        // RtPrimitiveFlags
+    int32_t material;
+    int32_t _pad0;
+    double inv_radius;    // sphere: 1.0 / radius (sphere.rs:61 divides via reciprocal)
+    double _pad1[2];
+};
+static_assert(sizeof(Prim) == 128, "Prim must be 128 bytes");
+
+struct alignas(16) Material { // 64 B
+    int32_t kind;             // RtMaterialKind
+    int32_t texture;          // index into textures
+    int32_t tex_kind;         // RtTextureKind of `texture` (-1 for Dielectric)
+    int32_t needs_uv;         // texture tree contains an Image texture
+    double fuzz;
+    double ior;
+    double color[3];          // the texture's colour when tex_kind == SolidColor
+    double _pad;
+};
+static_assert(sizeof(Material) == 64, "Material must be 64 bytes");
+
+struct alignas(16) Texture { // 64 B
+    int32_t kind;
+    int32_t tex_even, tex_odd;
+    int32_t image, perlin, depth;
+    int32_t _pad[2];
+    double color[3];
+    double scale;
+};
+static_assert(sizeof(Texture) == 64, "Texture must be 64 bytes");
+
+struct Image {
+    const uint8_t *rgba; // device pointer, RGBA8 row-major, row 0 = top
+    int32_t width, height;
+};
+
+struct Perlin { // gradient table only: perm tables are folded into `index`
+    double ranvec[256][3];
+    int32_t perm_x[256], perm_y[256], perm_z[256];
+};
+
+struct Camera { // what get_ray reads (camera.rs:326-337)
+    double origin[3], ulc[3], right[3], up[3], horizontal[3], vertical[3];
+    double lens_radius;
+};
+
+struct Background {
+    int32_t kind, _pad;
+    double top[3], bottom[3];
+};
+
+// Kernel argument block (passed by value -> kernarg segment, scalar loads).
+struct TraceArgs {
+    const Prim *prims;
+    const Material *materials;
+    const Texture *textures;
+    const Image *images;
+    const Perlin *perlins;
+    int32_t n_prims, n_materials, n_textures, n_images, n_perlins;
+    int32_t width, height;       // full image
+    int32_t samples, max_depth;
+    int32_t sample_begin, sample_end; // this launch accumulates samples [begin, end)
+    int32_t strip_rows, strip_count, strip_index;
+    int32_t owned_rows;          // number of image rows this launch covers
+    uint32_t seed_lo, seed_hi;
+    Camera cam;
+    Background bg;
+    double *accum;               // [height][width][3] running sums (owned rows only written)
+    unsigned long long *segments; // global segment counter
+};
+
+} // namespace rtdev

@@ -1,0 +1,175 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the
+same seeded inputs.
+
+Tolerance: BASELINE.json's north star states per-channel |delta| < 1e-3 at a
+fixed seed, on the post-tone-map float image.  Both sides compute in f64 with
+the same addressed random draws, so the expected difference is ~1e-13; the
+tests assert the stated 1e-3 on every pixel AND a much tighter bound on the
+bulk, so that a real divergence cannot hide under the tolerance.
+"""
+import numpy as np
+import pytest
+
+import scenes_py as S
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3          # the north star's per-channel tolerance
+TIGHT = 1e-9        # what f64-vs-f64 with identical draws should really achieve
+
+
+def _both(rt, orc, scene_fn, width, height, samples, seed=1, max_depth=20, use_bvh=1, **kw):
+    bundle, cam, tm = scene_fn()
+    camera = S.camera_for(cam, width, height)
+    params = S.abi.render_params(width, height, samples, max_depth=max_depth, seed=seed, **kw)
+    ref, ref_segs = orc.render(bundle.desc, camera, params, use_bvh=use_bvh)
+    scene = rt.Scene(bundle)
+    try:
+        got = scene.render_frame(camera, params)
+        stats = scene.last_stats()
+    finally:
+        scene.close()
+    kind = {"None": orc.ORC_TM_NONE, "Aces": orc.ORC_TM_ACES}[tm]
+    return orc.tone_map(kind, ref), orc.tone_map(kind, got), ref_segs, stats
+
+
+def _assert_parity(ref, got):
+    assert np.isfinite(got).all()
+    diff = np.abs(ref - got)
+    assert diff.max() < TOL, "max |delta| = %g" % diff.max()
+    # bulk must agree to rounding: at most a handful of pixels may carry a
+    # branch flip (ulp-level libm / FMA differences at a comparison)
+    frac_loose = float((diff.max(axis=-1) > TIGHT).mean())
+    assert frac_loose < 1e-3, "fraction of pixels beyond %g: %g" % (TIGHT, frac_loose)
+
+
+# use_bvh = 0 for the two-box scene: the oracle's BVH reproduces RotateY's
+# mis-sized bounding box (rotate_y.rs:66-90, SURVEY B-14) and so culls a thin
+# sliver of each box; the device path intersects the true geometry.  The linear
+# scan is the reference's own closest-hit semantics without that culling.
+@pytest.mark.parametrize("scene_fn,w,h,spp,use_bvh", [
+    (S.cornell_box, 160, 90, 32, 1),
+    (S.three_balls, 160, 90, 32, 1),
+    (S.two_balls, 96, 54, 16, 1),
+    (S.cornell_box_boxes, 160, 90, 16, 0),
+])
+def test_frame_matches_oracle(rt, orc, gpu, scene_fn, w, h, spp, use_bvh):
+    ref, got, ref_segs, stats = _both(rt, orc, scene_fn, w, h, spp, use_bvh=use_bvh)
+    _assert_parity(ref, got)
+    assert stats.samples == w * h * spp
+    # same paths => same number of scene.hit evaluations (allow a few flips)
+    assert abs(int(stats.segments) - ref_segs) <= max(4, ref_segs // 100000)
+
+
+def test_baseline_config_1_shape(rt, orc, gpu):
+    """BASELINE config 1: three_balls 400x225x16 (non-multiple-of-16 height)."""
+    ref, got, ref_segs, stats = _both(rt, orc, S.three_balls, 400, 225, 16)
+    _assert_parity(ref, got)
+
+
+@pytest.mark.parametrize("seed", [2, 3, 0xDEADBEEFCAFE])
+def test_seeds(rt, orc, gpu, seed):
+    ref, got, _, _ = _both(rt, orc, S.cornell_box, 64, 36, 8, seed=seed)
+    _assert_parity(ref, got)
+
+
+@pytest.mark.parametrize("max_depth", [0, 1, 2, 5])
+def test_depth_exhaustion_is_white(rt, orc, gpu, max_depth):
+    """renderer.rs:48-55: depth 0 returns (1,1,1), also with tiny max_depth."""
+    ref, got, _, _ = _both(rt, orc, S.cornell_box, 64, 36, 8, max_depth=max_depth)
+    _assert_parity(ref, got)
+    if max_depth == 0:
+        assert np.allclose(got, orc.tone_map(orc.ORC_TM_ACES, np.ones_like(got)))
+
+
+def test_odd_sizes(rt, orc, gpu):
+    for w, h in ((17, 9), (33, 31), (2, 2)):
+        ref, got, _, _ = _both(rt, orc, S.three_balls, w, h, 4)
+        _assert_parity(ref, got)
+
+
+def test_strips_assemble_to_full_frame(rt, orc, gpu):
+    """Multi-GPU row ownership: N strip renders == one full render, bit for bit
+    (the RNG is keyed by the global pixel index)."""
+    bundle, cam, _ = S.cornell_box()
+    w, h, spp = 96, 70, 8
+    camera = S.camera_for(cam, w, h)
+    scene = rt.Scene(bundle)
+    try:
+        full = scene.render_frame(camera, S.abi.render_params(w, h, spp))
+        for count, rows in ((2, 8), (3, 8), (8, 8), (4, 16)):
+            acc = np.full_like(full, -1.0)
+            for idx in range(count):
+                p = S.abi.render_params(w, h, spp, strip_rows=rows, strip_count=count, strip_index=idx)
+                part = scene.render_frame(camera, p)
+                own = ((np.arange(h) // rows) % count) == idx
+                assert (part[~own] == 0).all()  # unowned rows untouched in the zeroed buffer
+                acc[own] = part[own]
+            assert np.array_equal(acc, full)
+    finally:
+        scene.close()
+
+
+def test_tile_stream_matches_frame(rt, orc, gpu):
+    """rt_render emits cpu.rs:73-115's tile grid; stitched tiles == the frame."""
+    bundle, cam, _ = S.three_balls()
+    w, h, spp = 100, 45, 4
+    camera = S.camera_for(cam, w, h)
+    params = S.abi.render_params(w, h, spp, tiles_w=10, tiles_h=10)
+    scene = rt.Scene(bundle)
+    try:
+        frame = scene.render_frame(camera, params)
+        tiles = scene.render_tiles(camera, params)
+    finally:
+        scene.close()
+    assert len(tiles) == 100
+    # column-major order, last row absorbs the remainder (45 = 9*4 + 9)
+    assert [(t[0], t[1]) for t in tiles[:3]] == [(0, 0), (4, 0), (8, 0)]
+    assert tiles[9][3] == 9 and tiles[9][2] == 10
+    stitched = np.zeros_like(frame)
+    for r, c, tw, th, arr in tiles:
+        stitched[r:r + th, c:c + tw] = arr
+    assert np.array_equal(stitched, frame)
+
+
+def test_cancel_before_start_returns_cancel_event(rt, orc, gpu):
+    import ctypes as C
+    bundle, cam, _ = S.two_balls()
+    camera = S.camera_for(cam, 32, 18)
+    params = S.abi.render_params(32, 18, 2, tiles_w=2, tiles_h=2)
+    scene = rt.Scene(bundle)
+    try:
+        flag = C.c_int(1)
+        with pytest.raises(rt.RtError) as e:
+            scene.render_tiles(camera, params, cancel=C.pointer(flag))
+        assert e.value.code == S.abi.RT_ERR_CANCEL_EVENT  # cpu.rs:82-85
+    finally:
+        scene.close()
+
+
+def test_full_size_properties(rt, orc, gpu):
+    """BASELINE config 3 size (1920x1080) at reduced spp: properties that do
+    not need the oracle at full size + an oracle check on a row band."""
+    bundle, cam, _ = S.cornell_box()
+    w, h, spp = 1920, 1080, 4
+    camera = S.camera_for(cam, w, h)
+    params = S.abi.render_params(w, h, spp)
+    scene = rt.Scene(bundle)
+    try:
+        a = scene.render_frame(camera, params)
+        b = scene.render_frame(camera, params)
+        stats = scene.last_stats()
+    finally:
+        scene.close()
+    assert np.array_equal(a, b)                      # deterministic
+    assert np.isfinite(a).all() and (a >= 0).all()
+    assert (a[:, :300] == 0).all() and (a[:, -300:] == 0).all()  # black outside the box
+    assert stats.samples == w * h * spp
+    assert 3.0 < stats.segments / stats.samples < 4.0  # SURVEY: ~3.5 segments/sample
+    # oracle on a band of rows through the light (strip ownership keeps it cheap)
+    band = S.abi.render_params(w, h, spp, strip_rows=8, strip_count=135, strip_index=20)
+    ref, _ = orc.render(bundle.desc, camera, band)
+    rows = ((np.arange(h) // 8) % 135) == 20
+    d = np.abs(ref[rows] - a[rows])
+    assert d.max() < TOL
+    assert float((d.max(axis=-1) > TIGHT).mean()) < 1e-3
