@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s of the MI355X render path on BASELINE.json's workload.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4]
+
+A "step" is one full render of the workload frame: rt_render_frame_device on
+this rank's row strips (+ the RCCL gather of finished strips to rank 0 when
+N > 1).  Scene, camera and output buffer are resident in HBM before the timed
+region starts.  Rank 0 prints ONE JSON line.
+
+Default workload = BASELINE.json configs[2] (cornell_box.yml, 1920x1080, 1024
+spp, max_depth 20, Aces): it is the configuration the north star's target is
+quoted on and it fits one GPU.  `--workload c2|c4` select configs[1]/[3].
+
+Scaling is STRONG: the frame is fixed, N GPUs split its rows (8-row strips,
+interleaved), so value = W*H*spp / time-of-the-slowest-rank.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+STRIP_ROWS = 8
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+BYTES_PER_SEGMENT_F64 = 192.0  # 96-B f64 ray record read + written per segment
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4"])
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def load_workload(host, name, spp_override):
+    table = {
+        "c2": ("three_balls.yml", "config_c2.yml"),
+        "c3": ("cornell_box.yml", "config_c3.yml"),
+        "c4": ("noise_and_textures.yml", "config_c4.yml"),
+    }
+    scene_file, config_file = table[name]
+    session = host.Session(os.path.join(ROOT, "scenes", config_file),
+                           scene=os.path.join(ROOT, "scenes", scene_file))
+    if spp_override:
+        session.params.samples = spp_override
+    return session, "%s %dx%d %dspp max_depth %d" % (
+        scene_file, session.params.width, session.params.height, session.params.samples,
+        session.params.max_depth)
+
+
+def cpu_baseline(session, seconds):
+    """Times the CPU oracle (port of CpuRenderer, all host cores) on a bounded
+    sample of the same workload: same scene/resolution, reduced spp."""
+    from oracle import oracle_ctypes as orc
+    abi = importlib.import_module("racer-tracer_amd.abi")
+    p = abi.RtRenderParams.from_buffer_copy(session.params)
+    p.strip_count = 0
+    p.samples = 1
+    t0 = time.time()
+    orc.render(session.desc, session.camera, p)
+    t1 = max(time.time() - t0, 1e-3)
+    spp = int(max(1, min(512, seconds / t1)))
+    p.samples = spp
+    t0 = time.time()
+    _, segs = orc.render(session.desc, session.camera, p)
+    dt = time.time() - t0
+    n = p.width * p.height * spp
+    return {"value": round(n / dt / 1e6, 3), "unit": "Msamples/s",
+            "cores": min(orc.lib().orc_online_cores(), max(1, p.tiles_w) * max(1, p.tiles_h)),
+            "online_cores": orc.lib().orc_online_cores(), "kind": "port",
+            "sample": "same scene and %dx%d frame at %d spp (%.1f s, %.2f segments/sample)"
+                      % (p.width, p.height, spp, dt, segs / n)}
+
+
+def main():
+    args = parse()
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
+                     "--nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: there is no CPU fallback for the render path")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    rt = importlib.import_module("racer-tracer_amd")
+    host = importlib.import_module("racer-tracer_amd.host")
+    session, workload = load_workload(host, args.workload, args.spp)
+    p = session.params
+    W, H, spp = p.width, p.height, p.samples
+    p.strip_rows, p.strip_count, p.strip_index = STRIP_ROWS, world, rank
+
+    scene = rt.Scene(session, device=local)
+    frame = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
+    strips = importlib.import_module("racer-tracer_amd.strips")
+    gatherer = strips.StripGather(H, W, STRIP_ROWS, world, rank, "cuda", dist)
+    stream = torch.cuda.current_stream()
+    kernel_ms, segments = [], []
+
+    def step(record):
+        # trace + resolve on torch's current stream, then the one collective of the path
+        scene.render_frame_device(session.camera, p, frame.data_ptr(), stream.cuda_stream)
+        gatherer.gather(frame)
+        if record:
+            st = scene.last_stats()  # HIP events on the launch stream
+            kernel_ms.append(st.kernel_ms)
+            segments.append(int(st.segments))
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        seg_t = torch.tensor([float(sum(segments))], dtype=torch.float64, device="cuda")
+        dist.all_reduce(seg_t, op=dist.ReduceOp.SUM)
+        total_segments = float(seg_t.item())
+        k_t = torch.tensor([sum(kernel_ms)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(k_t, op=dist.ReduceOp.MAX)
+        kernel_total_ms = float(k_t.item())
+    else:
+        total_segments = float(sum(segments))
+        kernel_total_ms = sum(kernel_ms)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = W * H * spp / (elapsed / args.steps) / 1e6
+        seg_per_step = total_segments / args.steps
+        k_ms = kernel_total_ms / args.steps
+        achieved = BYTES_PER_SEGMENT_F64 * seg_per_step / (k_ms * 1e-3) / 1e9 / world  # GB/s per GPU
+        out = {
+            "metric": "Msamples/s (W*H*spp/s) at 1920x1080",
+            "value": round(value, 2),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic (the reference's own scene YAML; counter-based RNG, seed %d)" % p.seed,
+            "config": {"workload": workload, "strip_rows": STRIP_ROWS,
+                       "parallelism": "image rows interleaved over %d GPU(s)%s"
+                                      % (world, ", RCCL gather to rank 0" if world > 1 else "")},
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "kernel": "k_trace_f64",
+                "kernel_ms": round(k_ms, 3),
+                "segments_per_launch": seg_per_step / world,
+                "bytes_per_segment": BYTES_PER_SEGMENT_F64,
+                "gsegments_per_s": round(seg_per_step / (k_ms * 1e-3) / 1e9, 3),
+                "note": "achieved = algorithmic ray-state bytes (192 B/segment, SURVEY 8d) / kernel time; "
+                        "the kernel keeps ray state in registers, so real HBM traffic is the framebuffer only",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(session, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    scene.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
