@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Extracts the only reference-PRODUCED data points into a small JSON fixture.
+
+The reference cannot be built or run here (Rust, no toolchain; windowed;
+unseeded), so its own outputs are limited to the 600x600 `SavePng` screenshots
+under /root/reference/assets/.  This script reads those PNG files as DATA with
+PIL (nothing from the reference is executed) and stores
+
+  * a grid of sky pixels of three_balls.png / noise_and_textures.png (RGBA8):
+    sky pixels do not depend on the random jitter beyond rounding, so they pin
+    camera basis, pixel->(u,v) mapping, Sky, sqrt gamma, tone map None and the
+    truncating x255 quantisation;
+  * 4x4 block means of three_balls.png / cornell_box.png /
+    noise_and_textures.png (weak statistical goldens);
+  * a 16x8 grid of texels of resources/images/earthmap.jpg as decoded by PIL
+    (libjpeg-turbo), to pin the library's own baseline-JPEG decoder.
+
+Run in the build container (needs /root/reference): writes
+tests/golden/reference_assets.json.
+"""
+import json
+import os
+
+import numpy as np
+from PIL import Image
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    out = {"source": "sakarias88/racer-tracer assets/*.png and resources/images/earthmap.jpg (MIT), read with PIL",
+           "sky_pixels": {}, "block_means": {}, "earthmap_texels": {}}
+    for name in ("three_balls", "noise_and_textures"):
+        img = np.array(Image.open(os.path.join(REF, "assets", name + ".png")).convert("RGBA"))
+        assert img.shape == (600, 600, 4)
+        pts = []
+        ys = (0, 50, 100, 150, 190) if name == "three_balls" else (0, 20, 40)
+        for y in ys:
+            for x in (0, 150, 300, 450, 599):
+                pts.append({"x": x, "y": y, "rgba": [int(v) for v in img[y, x]]})
+        out["sky_pixels"][name] = pts
+    for name in ("three_balls", "cornell_box", "noise_and_textures"):
+        img = np.array(Image.open(os.path.join(REF, "assets", name + ".png")).convert("RGB")).astype(np.float64) / 255.0
+        bm = img.reshape(4, 150, 4, 150, 3).mean(axis=(1, 3))
+        out["block_means"][name] = np.round(bm, 5).tolist()
+    earth = np.array(Image.open(os.path.join(REF, "resources", "images", "earthmap.jpg")).convert("RGBA"))
+    out["earthmap_texels"] = {"width": int(earth.shape[1]), "height": int(earth.shape[0]), "step": 64,
+                              "offset": 17,
+                              "rgba": earth[17::64, 17::64].reshape(-1, 4).tolist(),
+                              "sum_rgb": [int(v) for v in earth[..., :3].reshape(-1, 3).sum(axis=0)]}
+    with open(os.path.join(HERE, "reference_assets.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote reference_assets.json")
+
+
+if __name__ == "__main__":
+    main()

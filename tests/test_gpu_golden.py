@@ -1,0 +1,84 @@
+"""GPU vs the COMMITTED golden frames (tests/golden/oracle_frames.npz) for all
+seven shipped scenes, driven through the C++ scene loader and the C ABI — the
+same route the CLI and bench.py take.  Also the post path on real renders."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import make_oracle_fixtures as fx  # noqa: E402
+
+GOLD = np.load(os.path.join(ROOT, "tests", "golden", "oracle_frames.npz"))
+TOL = 1e-3      # north star: per-channel |delta| < 1e-3 on the tone-mapped image
+TIGHT = 1e-9
+
+
+@pytest.fixture(scope="module")
+def host():
+    return importlib.import_module("racer-tracer_amd.host")
+
+
+@pytest.mark.parametrize("name", sorted(fx.SCENES))
+def test_gpu_matches_committed_oracle_frame(rt, host, gpu, name):
+    s, p, _ = fx.load(host, name)
+    cam = fx.camera_for(host, s, p)
+    scene = rt.Scene(s)
+    try:
+        got = scene.render_frame(cam, p)
+        stats = scene.last_stats()
+    finally:
+        scene.close()
+    gold = GOLD[name + "_frame"]
+    d = np.abs(s.tone_map(got) - s.tone_map(gold))
+    d = np.where(np.isnan(d), 0.0, d)   # Reinhard-style 0/0 on black pixels is NaN on both sides
+    assert np.isfinite(got).all()
+    assert d.max() < TOL, (name, d.max())
+    assert float((d.max(axis=-1) > TIGHT).mean()) < 2e-3, name
+    assert abs(int(stats.segments) - int(GOLD[name + "_segments"])) <= 4
+
+
+def test_noise_and_textures_full_resolution_band(rt, host, orc, gpu):
+    """BASELINE config 4 at full width, reduced spp: Perlin + image texture +
+    checker + glass against the live oracle on a band of rows."""
+    s = host.Session(os.path.join(ROOT, "scenes", "config_c4.yml"),
+                     scene=os.path.join(ROOT, "scenes", "noise_and_textures.yml"))
+    p = s.params
+    p.samples = 4
+    scene = rt.Scene(s)
+    try:
+        got = scene.render_frame(s.camera, p)
+    finally:
+        scene.close()
+    p.strip_rows, p.strip_count, p.strip_index = 8, 45, 22     # every 45th strip: 3 bands of 8 rows
+    ref, _ = orc.render(s.desc, s.camera, p)
+    rows = ((np.arange(p.height) // 8) % 45) == 22
+    d = np.abs(ref[rows] - got[rows])
+    assert d.max() < TOL
+    assert float((d.max(axis=-1) > TIGHT).mean()) < 2e-3
+
+
+def test_render_to_png_end_to_end(rt, host, gpu, tmp_path):
+    """renderer -> tone map -> SavePng, as main.rs:148-158 wires it."""
+    from PIL import Image
+    s, p, _ = fx.load(host, "cornell_box")
+    cam = fx.camera_for(host, s, p)
+    scene = rt.Scene(s)
+    try:
+        tiles = scene.render_tiles(cam, p)
+    finally:
+        scene.close()
+    frame = np.zeros((p.height, p.width, 3))
+    for r, c, w, h, arr in tiles:                      # ScreenBuffer::update (image_buffer.rs:135-170)
+        frame[r:r + h, c:c + w] = s.tone_map(arr)
+    path = s.save_png(frame, str(tmp_path))
+    img = np.array(Image.open(path))
+    gold = host.pack_rgba8(s.tone_map(GOLD["cornell_box_frame"]))
+    assert img.shape == gold.shape
+    assert np.abs(img.astype(int) - gold.astype(int)).max() <= 1   # truncation may flip an LSB at 1e-13 differences
+    assert (img != gold).mean() < 1e-3
