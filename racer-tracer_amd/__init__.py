@@ -15,7 +15,8 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libracer_tracer_amd.so")
+# RACER_TRACER_AMD_LIB lets a developer point at another build of the same ABI
+LIB_PATH = os.environ.get("RACER_TRACER_AMD_LIB", os.path.join(_HERE, "lib", "libracer_tracer_amd.so"))
 
 
 class RtError(RuntimeError):

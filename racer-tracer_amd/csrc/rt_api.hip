@@ -18,6 +18,12 @@ extern "C" hipError_t rtdev_launch_trace(const rtdev::TraceArgs *args, int prims
 extern "C" hipError_t rtdev_launch_resolve(const double *accum, double *out, int width, int height,
                                            int strip_rows, int strip_count, int strip_index, int samples,
                                            hipStream_t stream);
+extern "C" int rtdev_pool_blocks_per_cu(int prims_class, int textured, int specular);
+extern "C" hipError_t rtdev_launch_trace_pool(const rtdev::TraceArgs *args, int prims_class, int textured, int specular,
+                                              unsigned blocks, hipStream_t stream);
+extern "C" hipError_t rtdev_launch_resolve_chunks(const double *partial, double *out, int width, int height, int n_chunks,
+                                                  int strip_rows, int strip_count, int strip_index, int samples,
+                                                  hipStream_t stream);
 
 namespace {
 
@@ -69,7 +75,14 @@ struct RtScene {
     int textured = 0; // some material's texture is not a plain SolidColor
     int specular = 0; // some material is Metal or Dielectric
 
-    DevBuf<double> accum;  // running sums, W*H*3
+    // pooled kernel (default): persistent grid = CUs x resident blocks of the variant
+    bool use_v1 = false;   // env RT_TRACE_KERNEL=v1: the lane-per-pixel kernel
+    int num_cus = 0, pool_blocks_per_cu = 1;
+    DevBuf<double> partial;       // [chunks][H][W][3] per-chunk sums
+    DevBuf<unsigned int> queue;   // one item counter per launch of a render call
+    int last_chunks = 0;
+
+    DevBuf<double> accum;  // running sums, W*H*3 (v1 kernel)
     DevBuf<double> frame;  // resolved frame for the host-output entry points
     DevBuf<unsigned long long> segments;
     hipStream_t stream = nullptr; // used by rt_render_frame / rt_render
@@ -212,25 +225,74 @@ int enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, 
                    hipStream_t stream, int batch, const volatile int *cancel) {
     RT_HIP(hipSetDevice(s->device));
     size_t n = (size_t)p->width * (size_t)p->height * 3;
-    if (s->accum.count < n) RT_HIP(s->accum.alloc(n));
     rtdev::TraceArgs a;
     fill_args(s, camera, p, a);
-    RT_HIP(hipMemsetAsync(s->segments.ptr, 0, sizeof(unsigned long long), stream));
-    RT_HIP(hipEventRecord(s->ev_begin, stream));
-    int launches = 0;
     if (batch <= 0 || batch > p->samples) batch = p->samples;
-    for (int b = 0; b < p->samples; b += batch) {
-        if (cancel && *cancel) return RT_ERR_CANCEL_EVENT;
-        a.sample_begin = b;
-        a.sample_end = b + batch < p->samples ? b + batch : p->samples;
-        RT_HIP(rtdev_launch_trace(&a, s->prims_class, s->textured, s->specular, stream));
-        ++launches;
-        if (cancel) RT_HIP(hipStreamSynchronize(stream)); // so the next poll is meaningful
+    const int n_batches = (p->samples + batch - 1) / batch;
+    int launches = 0;
+    if (s->use_v1) {
+        if (s->accum.count < n) RT_HIP(s->accum.alloc(n));
+        a.accum = s->accum.ptr;
+        RT_HIP(hipMemsetAsync(s->segments.ptr, 0, sizeof(unsigned long long), stream));
+        RT_HIP(hipEventRecord(s->ev_begin, stream));
+        for (int b = 0; b < p->samples; b += batch) {
+            if (cancel && *cancel) return RT_ERR_CANCEL_EVENT;
+            a.sample_begin = b;
+            a.sample_end = b + batch < p->samples ? b + batch : p->samples;
+            RT_HIP(rtdev_launch_trace(&a, s->prims_class, s->textured, s->specular, stream));
+            ++launches;
+            if (cancel) RT_HIP(hipStreamSynchronize(stream)); // so the next poll is meaningful
+        }
+        RT_HIP(hipEventRecord(s->ev_traced, stream));
+        RT_HIP(rtdev_launch_resolve(s->accum.ptr, out_device, p->width, p->height, a.strip_rows, a.strip_count,
+                                    a.strip_index, p->samples, stream));
+        RT_HIP(hipEventRecord(s->ev_resolved, stream));
+    } else {
+        // Work items = 8x8 tiles x sample chunks.  Chunks per batch: enough items
+        // that the end-of-launch tail is a small fraction (>= 16 items per resident
+        // wave), at least 16 samples each, at most 64 slices of `partial`.
+        a.tiles_x = (p->width + 7) / 8;
+        a.n_tiles = a.tiles_x * ((a.owned_rows + 7) / 8);
+        const long long resident_waves = (long long)s->num_cus * s->pool_blocks_per_cu * 4;
+        int want = a.n_tiles > 0 ? (int)((16 * resident_waves + a.n_tiles - 1) / a.n_tiles) : 1;
+        if (want < batch / 128) want = batch / 128;
+        if (want > batch / 16) want = batch / 16;
+        if (want > 64 / n_batches) want = 64 / n_batches;
+        if (want < 1) want = 1;
+        const int chunk_samples = (batch + want - 1) / want;
+        const int chunks_per_batch = (batch + chunk_samples - 1) / chunk_samples;
+        const int total_chunks = chunks_per_batch * n_batches;
+        if (s->partial.count < n * (size_t)total_chunks) RT_HIP(s->partial.alloc(n * (size_t)total_chunks));
+        if (s->queue.count < (size_t)n_batches) RT_HIP(s->queue.alloc((size_t)n_batches));
+        a.partial = s->partial.ptr;
+        a.chunk_samples = chunk_samples;
+        RT_HIP(hipMemsetAsync(s->segments.ptr, 0, sizeof(unsigned long long), stream));
+        RT_HIP(hipMemsetAsync(s->queue.ptr, 0, sizeof(unsigned int) * (size_t)n_batches, stream));
+        // a slice is only written for the pixels a launch covers; unowned rows are skipped by the resolve
+        RT_HIP(hipEventRecord(s->ev_begin, stream));
+        int chunks_done = 0;
+        for (int b = 0; b < p->samples; b += batch) {
+            if (cancel && *cancel) return RT_ERR_CANCEL_EVENT;
+            a.sample_begin = b;
+            a.sample_end = b + batch < p->samples ? b + batch : p->samples;
+            a.n_chunks = (a.sample_end - a.sample_begin + chunk_samples - 1) / chunk_samples;
+            a.chunk_base = chunks_done;
+            a.n_items = (uint32_t)a.n_chunks * (uint32_t)a.n_tiles;
+            a.queue = s->queue.ptr + launches;
+            unsigned blocks = (unsigned)(s->num_cus * s->pool_blocks_per_cu);
+            unsigned needed = (a.n_items + 3) / 4;
+            if (blocks > needed) blocks = needed;
+            RT_HIP(rtdev_launch_trace_pool(&a, s->prims_class, s->textured, s->specular, blocks, stream));
+            chunks_done += a.n_chunks;
+            ++launches;
+            if (cancel) RT_HIP(hipStreamSynchronize(stream)); // so the next poll is meaningful
+        }
+        RT_HIP(hipEventRecord(s->ev_traced, stream));
+        RT_HIP(rtdev_launch_resolve_chunks(s->partial.ptr, out_device, p->width, p->height, chunks_done, a.strip_rows,
+                                           a.strip_count, a.strip_index, p->samples, stream));
+        RT_HIP(hipEventRecord(s->ev_resolved, stream));
+        s->last_chunks = chunks_done;
     }
-    RT_HIP(hipEventRecord(s->ev_traced, stream));
-    RT_HIP(rtdev_launch_resolve(s->accum.ptr, out_device, p->width, p->height, a.strip_rows, a.strip_count,
-                                a.strip_index, p->samples, stream));
-    RT_HIP(hipEventRecord(s->ev_resolved, stream));
     s->last_stream = stream;
     s->has_stats = true;
     s->last_launches = launches;
@@ -302,6 +364,8 @@ void rt_scene_destroy(RtScene *s) {
     s->images.release();
     s->perlins.release();
     s->accum.release();
+    s->partial.release();
+    s->queue.release();
     s->frame.release();
     s->segments.release();
     if (s->ev_begin) (void)hipEventDestroy(s->ev_begin);
@@ -415,6 +479,11 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
         s->bg.top[k] = d->background.top[k];
         s->bg.bottom[k] = d->background.bottom[k];
     }
+    if (const char *k = getenv("RT_TRACE_KERNEL")) s->use_v1 = strcmp(k, "v1") == 0;
+    RT_HIP(hipDeviceGetAttribute(&s->num_cus, hipDeviceAttributeMultiprocessorCount, device));
+    s->pool_blocks_per_cu = rtdev_pool_blocks_per_cu(s->prims_class, s->textured, s->specular);
+    if (const char *k = getenv("RT_POOL_BLOCKS_PER_CU")) // developer knob for occupancy experiments
+        if (atoi(k) > 0) s->pool_blocks_per_cu = atoi(k);
     RT_HIP(s->segments.alloc(1));
     RT_HIP(hipMemset(s->segments.ptr, 0, sizeof(unsigned long long)));
     RT_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
@@ -468,7 +537,12 @@ int rt_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, RtTil
     if (s->frame.count < n) RT_HIP(s->frame.alloc(n));
     // with a cancel flag, trace in batches so the flag is polled about as often
     // as the reference polls it per tile row (cpu.rs:55)
-    int batch = cancel ? (p->samples > 16 ? 16 : p->samples) : 0;
+    int batch = 0;
+    if (cancel) { // at most 32 launches, at least 16 samples each
+        batch = (p->samples + 31) / 32;
+        if (batch < 16) batch = 16;
+        if (batch > p->samples) batch = p->samples;
+    }
     rc = enqueue_render(s, camera, p, s->frame.ptr, s->stream, batch, cancel);
     if (rc == RT_ERR_CANCEL_EVENT) { // cpu.rs:55-62: return Ok, no tile written
         (void)hipStreamSynchronize(s->stream);

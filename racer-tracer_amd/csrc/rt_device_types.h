@@ -84,6 +84,18 @@ struct TraceArgs {
     Background bg;
     double *accum;               // [height][width][3] running sums (owned rows only written)
     unsigned long long *segments; // global segment counter
+    // --- pooled kernel (k_trace_pool_f64) ---
+    // Work item = (8x8 pixel tile, chunk of samples); items are numbered
+    // chunk-major: item = chunk * n_tiles + tile.  Each item writes the sums of
+    // its samples to partial[chunk_base + chunk][pixel]; k_resolve adds the
+    // chunks in index order, so the result does not depend on scheduling.
+    double *partial;             // [n_chunks_total][height][width][3]
+    unsigned int *queue;         // item counter (zeroed before the launch)
+    uint32_t n_items;
+    int32_t n_chunks;            // chunks in this launch
+    int32_t chunk_base;          // index of this launch's first chunk in `partial`
+    int32_t chunk_samples;       // samples per chunk (the last one may be shorter)
+    int32_t tiles_x, n_tiles;    // 8x8 tiles over width x owned_rows
 };
 
 } // namespace rtdev

@@ -1,0 +1,353 @@
+// rt_trace_common.h — device-side building blocks shared by the trace
+// kernels: Vec3 maths, the addressed Philox RNG (include/rt_rng.h), primitive
+// intersection with the RotateY/Translate wrappers, hit records, textures.
+// Formulas follow SURVEY.md App. A; each function cites the Rust it mirrors.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rt_device_types.h"
+#include "../../include/rt_abi.h"
+#include "../../include/rt_rng.h"
+
+namespace rtdev {
+
+enum { PRIMS_RECTS = 0, PRIMS_SPHERES = 1, PRIMS_ANY = 2 };
+
+// Scene tables are never written while a trace kernel runs.  Reading them
+// through the constant address space lets the backend use scalar loads (s_load,
+// K$) whenever the index is wave-uniform — the closest-hit loop — instead of
+// per-lane vector loads with a vmcnt wait per primitive.
+#define RT_CONSTANT __attribute__((address_space(4)))
+__device__ __forceinline__ Prim load_prim_uniform(const Prim *table, int i) {
+    Prim p;
+    __builtin_memcpy(&p, (const RT_CONSTANT Prim *)(table + i), sizeof(Prim));
+    return p;
+}
+
+// ------------------------------------------------------------------ vec3
+struct d3 {
+    double x, y, z;
+};
+__device__ __forceinline__ d3 mk(double x, double y, double z) { return d3{x, y, z}; }
+__device__ __forceinline__ d3 ld3(const double *p) { return d3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ d3 operator+(d3 a, d3 b) { return d3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ d3 operator-(d3 a, d3 b) { return d3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ d3 operator-(d3 a) { return d3{-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ d3 operator*(d3 a, d3 b) { return d3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ d3 operator*(d3 a, double s) { return d3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ d3 operator*(double s, d3 a) { return d3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ double len2(d3 a) { return dot(a, a); }
+// vec3.rs:79-85 divides by the length
+__device__ __forceinline__ d3 unit(d3 a) {
+    double l = sqrt(len2(a));
+    return d3{a.x / l, a.y / l, a.z / l};
+}
+// 1/x and 1/sqrt(x) to ~1 ulp: hardware seed + two Newton steps (the same
+// refinement the compiler's full f64 division uses, without its scaling and
+// fix-up instructions).  Used where the reference divides several values by
+// one denominator; results differ from true division by an ulp or two.
+__device__ __forceinline__ double rcp_f64(double x) {
+    const double r0 = __builtin_amdgcn_rcp(x);
+    double r = fma(r0, fma(-x, r0, 1.0), r0);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return __builtin_isfinite(r) ? r : r0; // x = 0 or inf: keep the hardware's inf / 0 like a true division
+}
+__device__ __forceinline__ double rsqrt_f64(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    h = fma(h, r, h);
+    return h + h;
+}
+// vec3.rs:79-85 unit_vector with one reciprocal square root instead of a
+// square root and three divisions
+__device__ __forceinline__ d3 unit_fast(d3 a) {
+    double inv = rsqrt_f64(len2(a));
+    return d3{a.x * inv, a.y * inv, a.z * inv};
+}
+__device__ __forceinline__ d3 rcp3(d3 a) { return d3{rcp_f64(a.x), rcp_f64(a.y), rcp_f64(a.z)}; }
+__device__ __forceinline__ double comp(d3 a, int axis) { return axis == 0 ? a.x : (axis == 1 ? a.y : a.z); }
+
+// ------------------------------------------------------------------- RNG
+struct u4 {
+    uint32_t a, b, c, d;
+};
+
+__device__ __forceinline__ u4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                            uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)RT_PHILOX_M0 * c0;
+        uint64_t p1 = (uint64_t)RT_PHILOX_M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += RT_PHILOX_W0;
+        k1 += RT_PHILOX_W1;
+    }
+    return u4{c0, c1, c2, c3};
+}
+
+// (((u64)hi << 32 | lo) >> 11) * 2^-53, exactly (two exact conversions, exact sum)
+__device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
+    uint32_t top = hi >> 11;
+    uint32_t low = (hi << 21) | (lo >> 11);
+    return fma((double)top, 0x1p-21, (double)low * 0x1p-53);
+}
+
+struct PathRng {
+    uint32_t pixel, sample, k0, k1;
+    __device__ __forceinline__ u4 block(uint32_t segment, uint32_t purpose, uint32_t blk) const {
+        return philox4x32_10(pixel, sample, (segment << 8) | purpose, blk, k0, k1);
+    }
+};
+
+// vec3.rs:424-430 random_in_unit_sphere under the addressed-draw contract
+__device__ __forceinline__ d3 random_in_unit_sphere(const PathRng &rng, uint32_t segment) {
+    for (uint32_t i = 0;; ++i) {
+        u4 b0 = rng.block(segment, RT_RNG_SCATTER, 2 * i);
+        u4 b1 = rng.block(segment, RT_RNG_SCATTER, 2 * i + 1);
+        d3 p = mk(fma(2.0, u53(b0.a, b0.b), -1.0), fma(2.0, u53(b0.c, b0.d), -1.0),
+                  fma(2.0, u53(b1.a, b1.b), -1.0));
+        if (len2(p) >= 1.0) continue;
+        return p;
+    }
+}
+
+// --------------------------------------------------------------- geometry
+struct Hit {
+    d3 point, normal;
+    double u, v;
+    bool front;
+};
+
+__device__ __forceinline__ void set_face_normal(Hit &h, d3 dir, d3 outward) { // geometry.rs:49-56
+    h.front = dot(dir, outward) < 0.0;
+    h.normal = h.front ? outward : -outward;
+}
+
+__device__ __forceinline__ d3 rot_fwd(d3 a, double s, double c) { // rotate_y.rs:42-46
+    return mk(c * a.x - s * a.z, a.y, s * a.x + c * a.z);
+}
+__device__ __forceinline__ d3 rot_back(d3 a, double s, double c) { // rotate_y.rs:55-59
+    return mk(c * a.x + s * a.z, a.y, -s * a.x + c * a.z);
+}
+
+// One axis-aligned rect in its own frame; `axis` = constant axis.
+// xy_rect.rs:29-40 / xz_rect.rs / yz_rect.rs
+__device__ __forceinline__ bool rect_t(int axis, double a0, double a1, double b0, double b1, double k,
+                                       d3 o, d3 d, d3 inv_d, double t_min, double t_max, double &t_out) {
+    int ia = axis == 0 ? 1 : 0;
+    int ib = axis == 2 ? 1 : 2;
+    double t = (k - comp(o, axis)) * comp(inv_d, axis); // xy_rect.rs:31 divides; inv_d = 1/d per ray
+    if (t < t_min || t > t_max) return false;
+    double a = comp(o, ia) + t * comp(d, ia);
+    double b = comp(o, ib) + t * comp(d, ib);
+    if (a < a0 || a > a1 || b < b0 || b > b1) return false;
+    t_out = t;
+    return true;
+}
+
+// box.rs:22-71 side s of a Boxx: axis and (a0,a1,b0,b1,k)
+__device__ __forceinline__ void box_side(const double *p, int s, int &axis, double &a0, double &a1,
+                                         double &b0, double &b1, double &k) {
+    axis = 2 - (s >> 1);
+    if (axis == 2) { a0 = p[0]; a1 = p[3]; b0 = p[1]; b1 = p[4]; k = (s & 1) ? p[2] : p[5]; }
+    else if (axis == 1) { a0 = p[0]; a1 = p[3]; b0 = p[2]; b1 = p[5]; k = (s & 1) ? p[1] : p[4]; }
+    else { a0 = p[1]; a1 = p[4]; b0 = p[2]; b1 = p[5]; k = (s & 1) ? p[0] : p[3]; }
+}
+
+// Nearest t of primitive P in [t_min, t_max], wrappers applied
+// (translate.rs:31, rotate_y.rs:39-48).  aux = box side.
+template <int PRIMS>
+// inv_d = 1/d (component-wise) and inv_a = 1/|d|^2 are computed once per ray.
+__device__ __forceinline__ bool prim_t(const Prim &P, d3 o, d3 d, d3 inv_d, double inv_a, double t_min, double t_max,
+                                       double &t_out, int &aux) {
+    aux = 0;
+    if (PRIMS == PRIMS_RECTS) { // untransformed rects only: kind picks the axis
+        int kind = P.kind;
+        if (kind == RT_PRIM_XY_RECT) return rect_t(2, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, t_min, t_max, t_out);
+        if (kind == RT_PRIM_XZ_RECT) return rect_t(1, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, t_min, t_max, t_out);
+        return rect_t(0, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, t_min, t_max, t_out);
+    }
+    if (PRIMS == PRIMS_ANY) {
+        if (P.flags & RT_PRIM_HAS_TRANSLATE) o = o - ld3(P.tr);
+        if (P.flags & RT_PRIM_HAS_ROTATE_Y) {
+            o = rot_fwd(o, P.rot_sin, P.rot_cos);
+            d = rot_fwd(d, P.rot_sin, P.rot_cos);
+            inv_d = rcp3(d); // the rotation preserves |d|, so inv_a stands
+        }
+    }
+    switch (PRIMS == PRIMS_SPHERES ? (int)RT_PRIM_SPHERE : P.kind) {
+    case RT_PRIM_SPHERE: { // sphere.rs:39-59
+        d3 oc = o - ld3(P.p);
+        double a = len2(d);
+        double half_b = dot(oc, d);
+        double c = len2(oc) - P.p[3] * P.p[3];
+        double disc = half_b * half_b - a * c;
+        if (disc < 0.0) return false;
+        double sqrtd = sqrt(disc);
+        double root = (-half_b - sqrtd) * inv_a; // sphere.rs:52 divides by a
+        if (root < t_min || t_max < root) {
+            root = (-half_b + sqrtd) * inv_a;
+            if (root < t_min || t_max < root) return false;
+        }
+        t_out = root;
+        return true;
+    }
+    case RT_PRIM_XY_RECT: return rect_t(2, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, t_min, t_max, t_out);
+    case RT_PRIM_XZ_RECT: return rect_t(1, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, t_min, t_max, t_out);
+    case RT_PRIM_YZ_RECT: return rect_t(0, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, t_min, t_max, t_out);
+    default: { // box.rs:82-101
+        bool any = false;
+        double closest = t_max;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            int axis;
+            double a0, a1, b0, b1, k, t;
+            box_side(P.p, s, axis, a0, a1, b0, b1, k);
+            if (rect_t(axis, a0, a1, b0, b1, k, o, d, inv_d, t_min, closest, t)) {
+                closest = t;
+                aux = s;
+                any = true;
+            }
+        }
+        t_out = closest;
+        return any;
+    }
+    }
+}
+
+// sphere.rs:20-27; out of line: acos/atan2 are large and only image textures read u,v
+__device__ __noinline__ void sphere_uv(d3 outward, double &u, double &v) {
+    const double PI = 3.14159265358979323846;
+    double theta = acos(-outward.y);
+    double phi = atan2(-outward.z, outward.x) + PI;
+    u = phi / (2.0 * PI);
+    v = theta / PI;
+}
+
+// Rebuild the HitRecord of the winning primitive (geometry.rs:17-57).
+template <int PRIMS, bool TEXTURED>
+__device__ __forceinline__ Hit prim_hit_record(const Prim &P, d3 o, d3 d, double t, int aux, bool want_uv) {
+    d3 oo = o, dd = d;
+    const int flags = PRIMS == PRIMS_ANY ? P.flags : 0;
+    if (flags & RT_PRIM_HAS_TRANSLATE) oo = oo - ld3(P.tr);
+    if (flags & RT_PRIM_HAS_ROTATE_Y) {
+        oo = rot_fwd(oo, P.rot_sin, P.rot_cos);
+        dd = rot_fwd(dd, P.rot_sin, P.rot_cos);
+    }
+    Hit h;
+    h.point = oo + t * dd; // ray.rs:30-32
+    h.u = 0.0;
+    h.v = 0.0;
+    const int kind = PRIMS == PRIMS_SPHERES ? (int)RT_PRIM_SPHERE : P.kind;
+    if (PRIMS != PRIMS_RECTS && kind == RT_PRIM_SPHERE) {
+        d3 outward = (h.point - ld3(P.p)) * P.inv_radius; // sphere.rs:61
+        if (TEXTURED && want_uv) sphere_uv(outward, h.u, h.v);
+        set_face_normal(h, dd, outward);
+    } else {
+        int axis;
+        double a0, a1, b0, b1, k;
+        if (PRIMS == PRIMS_ANY && kind == RT_PRIM_BOX) {
+            box_side(P.p, aux, axis, a0, a1, b0, b1, k);
+        } else {
+            axis = kind == RT_PRIM_XY_RECT ? 2 : (kind == RT_PRIM_XZ_RECT ? 1 : 0);
+            a0 = P.p[0]; a1 = P.p[1]; b0 = P.p[2]; b1 = P.p[3];
+        }
+        if (TEXTURED && want_uv) { // xy_rect.rs:41-42
+            int ia = axis == 0 ? 1 : 0;
+            int ib = axis == 2 ? 1 : 2;
+            h.u = (comp(h.point, ia) - a0) / (a1 - a0);
+            h.v = (comp(h.point, ib) - b0) / (b1 - b0);
+        }
+        set_face_normal(h, dd, mk(axis == 0 ? 1.0 : 0.0, axis == 1 ? 1.0 : 0.0, axis == 2 ? 1.0 : 0.0));
+    }
+    if (flags & RT_PRIM_HAS_ROTATE_Y) { // rotate_y.rs:52-63 (face test vs the rotated ray)
+        h.point = rot_back(h.point, P.rot_sin, P.rot_cos);
+        set_face_normal(h, dd, rot_back(h.normal, P.rot_sin, P.rot_cos));
+    }
+    if (flags & RT_PRIM_HAS_TRANSLATE) { // translate.rs:34-37 (re-runs set_face_normal)
+        h.point = h.point + ld3(P.tr);
+        set_face_normal(h, d, h.normal);
+    }
+    return h;
+}
+
+// --------------------------------------------------------------- textures
+__device__ __forceinline__ double perlin_noise(const Perlin &pl, d3 p) { // noise.rs:57-96
+    double fx = floor(p.x), fy = floor(p.y), fz = floor(p.z);
+    double u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    int i = (int)fx, j = (int)fy, k = (int)fz; // saturating on AMDGCN like Rust's `as i32`
+    double uu = u * u * (3.0 - 2.0 * u);
+    double vv = v * v * (3.0 - 2.0 * v);
+    double ww = w * w * (3.0 - 2.0 * w);
+    double accum = 0.0;
+#pragma unroll
+    for (int di = 0; di < 2; ++di)
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+            for (int dk = 0; dk < 2; ++dk) {
+                int index = pl.perm_x[(uint32_t)(i + di) & 255u] ^ pl.perm_y[(uint32_t)(j + dj) & 255u] ^
+                            pl.perm_z[(uint32_t)(k + dk) & 255u];
+                const double *g = pl.ranvec[index & 255];
+                d3 weight = mk(u - di, v - dj, w - dk);
+                accum += (di * uu + (1 - di) * (1.0 - uu)) * (dj * vv + (1 - dj) * (1.0 - vv)) *
+                         (dk * ww + (1 - dk) * (1.0 - ww)) * dot(ld3(g), weight);
+            }
+    return accum;
+}
+
+__device__ __forceinline__ double perlin_turbulence(const Perlin &pl, d3 p, int depth) { // noise.rs:98-109
+    double accum = 0.0, weight = 1.0;
+    for (int o = 0; o < depth; ++o) {
+        accum += weight * perlin_noise(pl, p);
+        weight *= 0.5;
+        p = p * 2.0;
+    }
+    return fabs(accum);
+}
+
+__device__ __forceinline__ double clamp01(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
+
+__device__ __noinline__ d3 texture_value_slow(const TraceArgs &A, int ti, double u, double v, d3 p) {
+    Texture T = A.textures[ti];
+    if (T.kind == RT_TEX_CHECKERED) { // checkered.rs:32-42
+        double sines = sin(p.x * 10.0) * sin(p.y * 10.0) * sin(p.z * 10.0);
+        T = A.textures[sines < 0.0 ? T.tex_odd : T.tex_even];
+    }
+    if (T.kind == RT_TEX_IMAGE) { // texture/image.rs:28-51
+        Image img = A.images[T.image];
+        double uu = clamp01(u);
+        double vv = 1.0 - clamp01(v);
+        double i = uu * (double)img.width;
+        double j = vv * (double)img.height;
+        if (i >= (double)img.width) i = (double)img.width - 1.0;
+        if (j >= (double)img.height) j = (double)img.height - 1.0;
+        uint32_t xi = (uint32_t)i, yj = (uint32_t)j; // saturating, NaN -> 0
+        uchar4 px = reinterpret_cast<const uchar4 *>(img.rgba)[(size_t)yj * (size_t)img.width + xi];
+        double s = 1.0 / 255.0;
+        return mk((double)px.x * s, (double)px.y * s, (double)px.z * s);
+    }
+    if (T.kind == RT_TEX_NOISE) { // noise.rs:26-33
+        double f = 1.0 + sin(T.scale * p.z + 10.0 * perlin_turbulence(A.perlins[T.perlin], p, T.depth));
+        return (ld3(T.color) * 0.5) * f;
+    }
+    return ld3(T.color);
+}
+
+template <bool TEXTURED>
+__device__ __forceinline__ d3 texture_value(const TraceArgs &A, const Material &M, double u, double v, d3 p) {
+    if (!TEXTURED || M.tex_kind == RT_TEX_SOLID_COLOR) return ld3(M.color); // solid_color.rs:24-28
+    return texture_value_slow(A, M.texture, u, v, p);
+}
+
+} // namespace rtdev

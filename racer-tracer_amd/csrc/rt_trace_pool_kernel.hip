@@ -1,0 +1,405 @@
+// rt_trace_pool_kernel.hip — the default trace kernel (f64): persistent waves
+// over a queue of (8x8 pixel tile, sample chunk) items, lanes drawing paths
+// from the item's pool, wave-cooperative rejection sampling.
+//
+// Replaces CpuRenderer::raytrace's pixel x sample loop
+// (racer-tracer/src/renderer/cpu.rs:26-71) and the recursive ray_color
+// (renderer.rs:41-90).  Three ideas, all measured against the v1 kernel
+// (rt_trace_kernel.hip) on cornell_box 1080p:
+//
+// 1. PERSISTENT WAVES + ITEM QUEUE.  The grid is sized to what is resident
+//    (CUs x blocks per CU); every wave pulls items from one atomic counter
+//    until the queue is dry.  An item is a tile x a chunk of its samples, so
+//    the end-of-launch tail is one small item, not one whole tile x all spp.
+//
+// 2. LANES ARE NOT PIXELS.  Inside an item the 64 lanes share a pool of
+//    64 x chunk (pixel, sample) paths: whenever lanes have no path in flight a
+//    ballot + prefix count hands them the next pool entries.  No lane waits for
+//    the slowest pixel of its tile; ray state (origin, direction, throughput)
+//    lives in VGPRs and never touches HBM.  Finished samples are added to the
+//    tile's 64 pixel sums in LDS (ds_add_f64); the item's sums go to its own
+//    slice partial[chunk][pixel], and k_resolve adds slices in index order, so
+//    the frame is deterministic and independent of scheduling.
+//
+// 3. COOPERATIVE REJECTION SAMPLING.  random_in_unit_sphere (vec3.rs:424-430)
+//    loops until a candidate falls inside the sphere; per lane that is 1.9
+//    iterations on average but a wave pays for its slowest lane (~6.4).
+//    Because every draw is ADDRESSED (include/rt_rng.h) — candidate i of a
+//    path is a pure function of (pixel, sample, segment, i) — any lane can
+//    evaluate any lane's candidate.  Each round the lanes that still need a
+//    sample post a request in LDS, the 64 lanes split into groups that test
+//    consecutive candidates of one request each, and a ballot picks the first
+//    accepted candidate in stream order.  ~3 rounds instead of ~6.4, identical
+//    values (the accepted candidate is exactly the one the sequential loop
+//    would have stopped at).
+#include "rt_trace_common.h"
+
+namespace rtdev {
+
+__device__ __forceinline__ int lane_rank(uint64_t mask) { // set bits of `mask` below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+struct WaveLds {
+    double u[64];       // cpu.rs:35-36: the per-pixel horizontal jitter, (px + ju) / (W - 1)
+    double sum[64][3];  // per-pixel radiance sums of the current item
+    uint4 req[64];      // cooperative sampler requests: {pixel, sample, segment, next candidate}
+    int pix_of[64];     // pool slot -> lane-order pixel index, for tiles cut by the image edge
+};
+
+// vec3.rs:424-430 for every lane with `need`, evaluated by the whole wave.
+// Must be called by all 64 lanes (wave-uniform control flow).
+__device__ __forceinline__ d3 coop_random_in_unit_sphere(bool need, uint32_t pixel, uint32_t sample, uint32_t seg,
+                                                         uint32_t k0, uint32_t k1, int lane, uint4 *req) {
+    d3 result = mk(0.0, 0.0, 0.0);
+    uint32_t base = 0; // first untested candidate of this lane's request
+    uint64_t pending = __ballot(need);
+    while (pending != 0) {
+        const int n = __popcll(pending);
+        // group size q = 2^lg, the largest power of two with n * q <= 64
+        const int lg = n > 32 ? 0 : (n > 16 ? 1 : (n > 8 ? 2 : (n > 4 ? 3 : (n > 2 ? 4 : (n > 1 ? 5 : 6)))));
+        const int rank = lane_rank(pending);
+        if (need) req[rank] = make_uint4(pixel, sample, seg, base);
+        const int j = lane >> lg;              // request served by this lane
+        const int c = lane & ((1 << lg) - 1);  // candidate offset inside the group
+        const bool serving = j < n;
+        const uint4 r = req[serving ? j : 0];
+        const uint32_t i = r.w + (uint32_t)c;  // candidate index: blocks 2i and 2i+1 (rt_rng.h)
+        const u4 b0 = philox4x32_10(r.x, r.y, (r.z << 8) | RT_RNG_SCATTER, 2u * i, k0, k1);
+        const u4 b1 = philox4x32_10(r.x, r.y, (r.z << 8) | RT_RNG_SCATTER, 2u * i + 1u, k0, k1);
+        const d3 p = mk(fma(2.0, u53(b0.a, b0.b), -1.0), fma(2.0, u53(b0.c, b0.d), -1.0),
+                        fma(2.0, u53(b1.a, b1.b), -1.0));
+        const uint64_t accepted = __ballot(serving && len2(p) < 1.0);
+        // first accepted candidate of my own request, in stream order
+        const int first = need ? (rank << lg) : 0;
+        const uint64_t width_mask = lg == 6 ? ~0ull : ((1ull << (1 << lg)) - 1ull);
+        const uint64_t mine = need ? ((accepted >> first) & width_mask) : 0ull;
+        const bool got = mine != 0;
+        const int src = got ? first + __ffsll((unsigned long long)mine) - 1 : lane;
+        const double rx = __shfl(p.x, src, 64), ry = __shfl(p.y, src, 64), rz = __shfl(p.z, src, 64);
+        if (got) {
+            result = mk(rx, ry, rz);
+            need = false;
+        } else if (need) {
+            base += 1u << lg;
+        }
+        pending = __ballot(need);
+    }
+    return result;
+}
+
+template <int PRIMS, bool TEXTURED, bool SPECULAR>
+__global__ __launch_bounds__(256) void k_trace_pool_f64(const TraceArgs A) {
+    __shared__ WaveLds lds_all[4];
+    const int lane = threadIdx.x & 63;
+    WaveLds &L = lds_all[threadIdx.x >> 6];
+    unsigned int n_segments = 0;
+
+    for (;;) {
+        // ---- next item for this wave
+        uint32_t item = 0;
+        if (lane == 0) item = atomicAdd(A.queue, 1u);
+        item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
+        if (item >= A.n_items) break;
+        const uint32_t chunk = item / (uint32_t)A.n_tiles;
+        const uint32_t tile = item - chunk * (uint32_t)A.n_tiles;
+        const int ty = (int)(tile / (uint32_t)A.tiles_x);
+        const int tx = (int)tile - ty * A.tiles_x;
+        const int smp0 = A.sample_begin + (int)chunk * A.chunk_samples;
+        const int n_smp = min(A.chunk_samples, A.sample_end - smp0);
+
+        // ---- this lane's pixel of the tile (used for the pool table and the final store)
+        const int my_px = tx * 8 + (lane & 7);
+        const int my_vrow = ty * 8 + (lane >> 3);
+        int my_py = my_vrow;
+        if (A.strip_count > 1)
+            my_py = ((my_vrow / A.strip_rows) * A.strip_count + A.strip_index) * A.strip_rows + my_vrow % A.strip_rows;
+        const bool my_valid = my_px < A.width && my_vrow < A.owned_rows && my_py < A.height;
+        const uint32_t my_pixel = (uint32_t)my_py * (uint32_t)A.width + (uint32_t)my_px;
+        const uint64_t valid_mask = __ballot(my_valid);
+        const int n_valid = __popcll(valid_mask);
+        {
+            PathRng prng{my_pixel, RT_RNG_SAMPLE_PIXEL, A.seed_lo, A.seed_hi};
+            u4 bj = prng.block(0, RT_RNG_PIXEL, 0);
+            L.u[lane] = ((double)my_px + u53(bj.a, bj.b)) / (double)(A.width - 1); // cpu.rs:35-36
+            L.sum[lane][0] = 0.0;
+            L.sum[lane][1] = 0.0;
+            L.sum[lane][2] = 0.0;
+            if (my_valid) L.pix_of[lane_rank(valid_mask)] = lane;
+        }
+        const uint32_t total = (uint32_t)n_valid * (uint32_t)n_smp; // paths in this item's pool
+        uint32_t next = 0;
+
+        // ---- path state of this lane
+        bool alive = false;
+        int pix = 0;          // pixel of the tile (lane order) the current path belongs to
+        PathRng rng{0, 0, A.seed_lo, A.seed_hi};
+        d3 o = mk(0, 0, 0), d = o, T = o;
+        uint32_t seg = 0;
+
+        for (;;) {
+            // ---- hand pool entries to the lanes without a path (ballot + prefix count)
+            if (next < total) {
+                const uint64_t idle = __ballot(!alive);
+                const uint32_t w = next + (uint32_t)lane_rank(idle);
+                next += (uint32_t)__popcll(idle);
+                if (!alive && w < total) {
+                    int s_off;
+                    if (n_valid == 64) {
+                        pix = (int)(w & 63u);
+                        s_off = (int)(w >> 6);
+                    } else {
+                        s_off = (int)(w / (uint32_t)n_valid);
+                        pix = L.pix_of[w - (uint32_t)s_off * (uint32_t)n_valid];
+                    }
+                    const int px = tx * 8 + (pix & 7);
+                    const int vrow = ty * 8 + (pix >> 3);
+                    int py = vrow;
+                    if (A.strip_count > 1)
+                        py = ((vrow / A.strip_rows) * A.strip_count + A.strip_index) * A.strip_rows + vrow % A.strip_rows;
+                    rng.pixel = (uint32_t)py * (uint32_t)A.width + (uint32_t)px;
+                    rng.sample = (uint32_t)(smp0 + s_off);
+                    // cpu.rs:39-40 + camera.rs:326-337
+                    const u4 bc = rng.block(0, RT_RNG_CAMERA, 0);
+                    const double v = ((double)py + u53(bc.a, bc.b)) / (double)(A.height - 1);
+                    const double u = L.u[pix];
+                    d3 offset = mk(0.0, 0.0, 0.0);
+                    if (A.cam.lens_radius != 0.0) { // aperture 0: the disk is multiplied by 0 -> its draws are dead
+                        double rx, ry;
+                        for (uint32_t i = 0;; ++i) { // util.rs:25-39
+                            const u4 b = rng.block(0, RT_RNG_LENS, i);
+                            rx = fma(2.0, u53(b.a, b.b), -1.0);
+                            ry = fma(2.0, u53(b.c, b.d), -1.0);
+                            if (rx * rx + ry * ry >= 1.0) continue;
+                            break;
+                        }
+                        rx *= A.cam.lens_radius;
+                        ry *= A.cam.lens_radius;
+                        offset = ld3(A.cam.right) * rx + ld3(A.cam.up) * ry;
+                    }
+                    const d3 co = ld3(A.cam.origin);
+                    o = co + offset;
+                    d = ld3(A.cam.ulc) + u * ld3(A.cam.horizontal) - v * ld3(A.cam.vertical) - co - offset;
+                    // (ray time, camera.rs:335, is drawn by the oracle; nothing in scope reads it)
+                    T = mk(1.0, 1.0, 1.0);
+                    seg = 0;
+                    alive = true;
+                }
+            }
+            if (__ballot(alive) == 0) break; // pool dry and nothing in flight
+
+            // ---- one ray_color level for every lane with a path
+            d3 contrib = mk(0.0, 0.0, 0.0); // what the path adds to its pixel if it ends here
+            bool ended = false;
+            bool need_sphere = false;       // wants a random_in_unit_sphere sample
+            bool is_lambert = false, is_metal = false;
+            Hit h;
+            h.point = o;
+            h.normal = o;
+            h.u = h.v = 0.0;
+            h.front = true;
+            d3 albedo = mk(0.0, 0.0, 0.0);
+            double fuzz = 0.0;
+            if (alive) {
+                if (A.max_depth <= 0) { // renderer.rs:48-55 with max_depth 0
+                    contrib = T;
+                    ended = true;
+                } else {
+                    ++n_segments;
+                    double best_t = __builtin_inf(); // closest hit, t in [0.001, inf) (renderer.rs:58)
+                    int best = -1, best_aux = 0;
+                    const d3 inv_d = rcp3(d);
+                    const double inv_a = PRIMS == PRIMS_RECTS ? 0.0 : rcp_f64(len2(d));
+                    for (int i = 0; i < A.n_prims; ++i) {
+                        double t;
+                        int aux;
+                        if (prim_t<PRIMS>(load_prim_uniform(A.prims, i), o, d, inv_d, inv_a, 0.001, best_t, t, aux)) {
+                            best_t = t;
+                            best = i;
+                            best_aux = aux;
+                        }
+                    }
+                    if (best < 0) { // background_color.rs:27-33 / :45-48
+                        d3 bgc = ld3(A.bg.top);
+                        if (A.bg.kind == RT_BG_SKY) {
+                            const double t = 0.5 * (d.y * rsqrt_f64(len2(d)) + 1.0);
+                            bgc = (1.0 - t) * ld3(A.bg.top) + t * ld3(A.bg.bottom);
+                        }
+                        contrib = T * bgc;
+                        ended = true;
+                    } else {
+                        const Prim &P = A.prims[best];
+                        const Material &M = A.materials[P.material];
+                        h = prim_hit_record<PRIMS, TEXTURED>(P, o, d, best_t, best_aux, M.needs_uv != 0);
+                        const int kind = M.kind;
+                        if (kind == RT_MAT_DIFFUSE_LIGHT) { // diffuse_light.rs:25-37
+                            contrib = T * texture_value<TEXTURED>(A, M, h.u, h.v, h.point);
+                            ended = true;
+                        } else if (kind == RT_MAT_LAMBERTIAN) { // lambertian.rs:26-38 (direction below)
+                            albedo = texture_value<TEXTURED>(A, M, h.u, h.v, h.point);
+                            is_lambert = true;
+                            need_sphere = true;
+                        } else if (SPECULAR && kind == RT_MAT_METAL) { // metal.rs:26-43 (fuzz below)
+                            albedo = texture_value<TEXTURED>(A, M, h.u, h.v, h.point);
+                            fuzz = M.fuzz;
+                            is_metal = true;
+                            need_sphere = fuzz != 0.0; // fuzz 0 multiplies the sample by 0: its draws are dead
+                        } else if (SPECULAR) { // dialectric.rs:25-55
+                            const double ratio = h.front ? 1.0 / M.ior : M.ior;
+                            const d3 ud = unit_fast(d);
+                            const double cos_theta = fmin(dot(-ud, h.normal), 1.0);
+                            const double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+                            bool reflect_it = ratio * sin_theta > 1.0;
+                            if (!reflect_it) { // the draw happens only when refraction is possible
+                                double r0 = (1.0 - ratio) / (1.0 + ratio);
+                                r0 = r0 * r0;
+                                const double m = 1.0 - cos_theta;
+                                const double m2 = m * m;
+                                const double refl = r0 + (1.0 - r0) * (m2 * m2 * m);
+                                const u4 b = rng.block(seg, RT_RNG_DIELECTRIC, 0);
+                                reflect_it = refl > u53(b.a, b.b);
+                            }
+                            if (reflect_it) {
+                                d = ud - (2.0 * dot(ud, h.normal)) * h.normal;
+                            } else { // vec3.rs:416-422
+                                const d3 perp = ratio * (ud + cos_theta * h.normal);
+                                d = perp + (-sqrt(fabs(1.0 - len2(perp)))) * h.normal;
+                            }
+                            o = h.point;
+                        } else { // unreachable: the host picks SPECULAR whenever such a material exists
+                            ended = true;
+                        }
+                    }
+                }
+            }
+
+            // ---- the wave evaluates the rejection loops together (all 64 lanes arrive here)
+            const d3 sph = coop_random_in_unit_sphere(need_sphere, rng.pixel, rng.sample, seg, A.seed_lo, A.seed_hi,
+                                                      lane, L.req);
+
+            if (alive && !ended) {
+                if (is_lambert) { // lambertian.rs:27-33
+                    d3 dir = h.normal + unit_fast(sph);
+                    if (fabs(dir.x) < 1e-8 && fabs(dir.y) < 1e-8 && fabs(dir.z) < 1e-8) dir = h.normal;
+                    T = T * albedo;
+                    o = h.point;
+                    d = dir;
+                } else if (SPECULAR && is_metal) { // metal.rs:30-42
+                    const d3 ud = unit_fast(d);
+                    d3 dir = ud - (2.0 * dot(ud, h.normal)) * h.normal;
+                    if (need_sphere) dir = dir + fuzz * sph;
+                    if (dot(dir, h.normal) < 0.0) {
+                        contrib = mk(0.0, 0.0, 0.0);
+                        ended = true;
+                    } else {
+                        T = T * albedo;
+                        o = h.point;
+                        d = dir;
+                    }
+                }
+                // renderer.rs:48-55: the recursion's next level has depth 0 -> white
+                if (!ended && (int)++seg >= A.max_depth) {
+                    contrib = T;
+                    ended = true;
+                }
+            }
+            if (alive && ended) { // vec3.rs:38-42 Color::add into the pixel's sum
+                atomicAdd(&L.sum[pix][0], contrib.x);
+                atomicAdd(&L.sum[pix][1], contrib.y);
+                atomicAdd(&L.sum[pix][2], contrib.z);
+                alive = false;
+            }
+        }
+
+        // ---- item done: its sums go to its own slice of `partial`
+        if (my_valid) {
+            double *dst = A.partial + ((size_t)(A.chunk_base + (int)chunk) * (size_t)A.height * (size_t)A.width + (size_t)my_pixel) * 3;
+            dst[0] = L.sum[lane][0];
+            dst[1] = L.sum[lane][1];
+            dst[2] = L.sum[lane][2];
+        }
+    }
+
+    unsigned long long total_segments = n_segments; // one atomic per wave for the statistic
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) total_segments += __shfl_down(total_segments, off, 64);
+    if (lane == 0 && total_segments) atomicAdd(A.segments, total_segments);
+}
+
+// vec3.rs:119-125 scale_sqrt over the owned rows: out = sqrt(sum over chunks / samples),
+// chunks added in index order.
+__global__ __launch_bounds__(256) void k_resolve_chunks_f64(const double *__restrict__ partial, double *__restrict__ out,
+                                                            int width, int height, int n_chunks, int strip_rows,
+                                                            int strip_count, int strip_index, double scale) {
+    const size_t n = (size_t)width * (size_t)height * 3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (strip_count > 1) {
+            const int row = (int)(i / ((size_t)width * 3));
+            if ((row / strip_rows) % strip_count != strip_index) continue;
+        }
+        double acc = 0.0;
+        for (int c = 0; c < n_chunks; ++c) acc += partial[(size_t)c * n + i];
+        out[i] = sqrt(scale * acc);
+    }
+}
+
+} // namespace rtdev
+
+namespace {
+template <int PRIMS, bool TEXTURED, bool SPECULAR>
+void launch_pool_variant(const rtdev::TraceArgs &a, unsigned blocks, hipStream_t stream) {
+    hipLaunchKernelGGL((rtdev::k_trace_pool_f64<PRIMS, TEXTURED, SPECULAR>), dim3(blocks), dim3(256), 0, stream, a);
+}
+template <int PRIMS>
+void launch_pool_prims(const rtdev::TraceArgs &a, bool textured, bool specular, unsigned blocks, hipStream_t stream) {
+    if (textured) {
+        if (specular) launch_pool_variant<PRIMS, true, true>(a, blocks, stream);
+        else launch_pool_variant<PRIMS, true, false>(a, blocks, stream);
+    } else {
+        if (specular) launch_pool_variant<PRIMS, false, true>(a, blocks, stream);
+        else launch_pool_variant<PRIMS, false, false>(a, blocks, stream);
+    }
+}
+template <int PRIMS, bool TEXTURED, bool SPECULAR> int pool_blocks_per_cu() {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rtdev::k_trace_pool_f64<PRIMS, TEXTURED, SPECULAR>, 256, 0) != hipSuccess)
+        return 1;
+    return n < 1 ? 1 : n;
+}
+template <int PRIMS> int pool_blocks_prims(bool textured, bool specular) {
+    if (textured) return specular ? pool_blocks_per_cu<PRIMS, true, true>() : pool_blocks_per_cu<PRIMS, true, false>();
+    return specular ? pool_blocks_per_cu<PRIMS, false, true>() : pool_blocks_per_cu<PRIMS, false, false>();
+}
+} // namespace
+
+// Resident blocks per CU of the variant (the persistent grid is CUs x this).
+extern "C" int rtdev_pool_blocks_per_cu(int prims_class, int textured, int specular) {
+    switch (prims_class) {
+    case rtdev::PRIMS_RECTS: return pool_blocks_prims<rtdev::PRIMS_RECTS>(textured != 0, specular != 0);
+    case rtdev::PRIMS_SPHERES: return pool_blocks_prims<rtdev::PRIMS_SPHERES>(textured != 0, specular != 0);
+    default: return pool_blocks_prims<rtdev::PRIMS_ANY>(textured != 0, specular != 0);
+    }
+}
+
+extern "C" hipError_t rtdev_launch_trace_pool(const rtdev::TraceArgs *args, int prims_class, int textured, int specular,
+                                              unsigned blocks, hipStream_t stream) {
+    if (blocks == 0 || args->n_items == 0) return hipSuccess;
+    switch (prims_class) {
+    case rtdev::PRIMS_RECTS: launch_pool_prims<rtdev::PRIMS_RECTS>(*args, textured != 0, specular != 0, blocks, stream); break;
+    case rtdev::PRIMS_SPHERES: launch_pool_prims<rtdev::PRIMS_SPHERES>(*args, textured != 0, specular != 0, blocks, stream); break;
+    default: launch_pool_prims<rtdev::PRIMS_ANY>(*args, textured != 0, specular != 0, blocks, stream); break;
+    }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rtdev_launch_resolve_chunks(const double *partial, double *out, int width, int height, int n_chunks,
+                                                  int strip_rows, int strip_count, int strip_index, int samples,
+                                                  hipStream_t stream) {
+    size_t n = (size_t)width * (size_t)height * 3;
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    if (blocks > 4096u) blocks = 4096u;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(rtdev::k_resolve_chunks_f64, dim3(blocks), dim3(256), 0, stream, partial, out, width, height,
+                       n_chunks, strip_rows, strip_count, strip_index, 1.0 / (double)samples);
+    return hipGetLastError();
+}

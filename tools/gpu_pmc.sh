@@ -1,0 +1,41 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): one rocprofv3 PMC pass per counter group
+# over a short bench run (no --kernel-trace/--stats together with --pmc: the
+# pool refuses that combination).  Results: gpurun_out/pmc_<tag>/<group>/...
+# Usage: tools/gpu_pmc.sh <tag> "<counters group 1>" ["<counters group 2>" ...] -- [bench args]
+set -eo pipefail
+tag=$1
+shift
+groups=()
+while [ $# -gt 0 ] && [ "$1" != "--" ]; do groups+=("$1"); shift; done
+[ "$1" == "--" ] && shift
+export TMPDIR=/tmp
+cd "$(dirname "$0")/.."
+root=$(pwd)/gpurun_out/pmc_$tag
+g=0
+for counters in "${groups[@]}"; do
+    out=$root/g$g
+    mkdir -p "$out"
+    # shellcheck disable=SC2086
+    rocprofv3 --pmc $counters --output-format csv -d "$out" -o pmc -- python3 bench.py --no-cpu-baseline "$@" > "$out/bench_stdout.log" 2> "$out/rocprof_stderr.log" || { tail -20 "$out/rocprof_stderr.log"; exit 1; }
+    f=$(find "$out" -name '*counter_collection.csv' | sort | sed -n 1p)
+    echo "== group $g: $counters"
+    if [ -n "$f" ]; then
+        python3 - "$f" <<'EOF'
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in rows:
+    agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, cs in agg.items():
+    if "trace" not in k and "resolve" not in k:
+        continue
+    print(k)
+    for c, v in sorted(cs.items()):
+        print("   %-28s n=%d mean=%.6g" % (c, len(v), sum(v) / len(v)))
+EOF
+    else
+        echo "no counter_collection.csv"; ls -R "$out" | head
+    fi
+    g=$((g + 1))
+done
