@@ -318,36 +318,78 @@ __device__ __forceinline__ double perlin_turbulence(const Perlin &pl, d3 p, int 
 
 __device__ __forceinline__ double clamp01(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
 
-__device__ __noinline__ d3 texture_value_slow(const TraceArgs &A, int ti, double u, double v, d3 p) {
-    Texture T = A.textures[ti];
-    if (T.kind == RT_TEX_CHECKERED) { // checkered.rs:32-42
-        double sines = sin(p.x * 10.0) * sin(p.y * 10.0) * sin(p.z * 10.0);
-        T = A.textures[sines < 0.0 ? T.tex_odd : T.tex_even];
+// sin(x) for |x| up to ~1e6 with a 3-part Cody-Waite reduction by pi/2 (each
+// part has 33 significant bits, so k * part is exact for k < 2^20) and the
+// classic degree-13/14 kernels on [-pi/4, pi/4].  About 35 f64 instructions, no
+// table, no scratch — unlike the general-range library sin, whose Payne-Hanek
+// path forces 400+ bytes of scratch on every wave of the kernel.  Within ~1 ulp
+// of the reference's libm sin; checkered.rs only uses the sign of a product of
+// sines and noise.rs feeds sin(scale*z + 10*turb) of scene-sized arguments.
+__device__ __forceinline__ double sin_lean(double x) {
+    const double kd = rint(x * 0.63661977236758134308); // 2/pi
+    double r = fma(-kd, 1.57079632673412561417e+00, x);
+    r = fma(-kd, 6.07710050630396597660e-11, r);
+    r = fma(-kd, 2.02226624871116645580e-21, r);
+    const int q = (int)kd;
+    const double z = r * r;
+    // sine kernel
+    const double ps = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                        2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                          8.33333333332248946124e-03);
+    const double sn = fma(z * r, fma(z, ps, -1.66666666666666324348e-01), r);
+    // cosine kernel
+    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                               -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                                 -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double cs = 1.0 - fma(0.5, z, -(z * z) * pc);
+    const double v = (q & 1) ? cs : sn;
+    return (q & 2) ? -v : v;
+}
+
+// Noise through a Perlin table in global memory (scenes with more than one
+// Noise texture; the first table is staged in LDS by the pooled kernel).
+__device__ __forceinline__ double perlin_turbulence_global(const Perlin *pl, d3 p, int depth) {
+    return perlin_turbulence(*pl, p, depth);
+}
+
+// Texture::value for everything that is not a plain SolidColor.
+// lds_perlin: LDS copy of A.perlins[0], or nullptr.
+__device__ __forceinline__ d3 texture_value_full(const TraceArgs &A, const Perlin *lds_perlin, int ti, double u, double v,
+                                                 d3 p) {
+    const Texture *T = &A.textures[ti];
+    if (T->kind == RT_TEX_CHECKERED) { // checkered.rs:32-42
+        const double sines = sin_lean(p.x * 10.0) * sin_lean(p.y * 10.0) * sin_lean(p.z * 10.0);
+        T = &A.textures[sines < 0.0 ? T->tex_odd : T->tex_even];
     }
-    if (T.kind == RT_TEX_IMAGE) { // texture/image.rs:28-51
-        Image img = A.images[T.image];
-        double uu = clamp01(u);
-        double vv = 1.0 - clamp01(v);
+    const int kind = T->kind;
+    if (kind == RT_TEX_IMAGE) { // texture/image.rs:28-51
+        const Image img = A.images[T->image];
+        const double uu = clamp01(u);
+        const double vv = 1.0 - clamp01(v);
         double i = uu * (double)img.width;
         double j = vv * (double)img.height;
         if (i >= (double)img.width) i = (double)img.width - 1.0;
         if (j >= (double)img.height) j = (double)img.height - 1.0;
-        uint32_t xi = (uint32_t)i, yj = (uint32_t)j; // saturating, NaN -> 0
-        uchar4 px = reinterpret_cast<const uchar4 *>(img.rgba)[(size_t)yj * (size_t)img.width + xi];
-        double s = 1.0 / 255.0;
+        const uint32_t xi = (uint32_t)i, yj = (uint32_t)j; // saturating, NaN -> 0
+        const uchar4 px = reinterpret_cast<const uchar4 *>(img.rgba)[(size_t)yj * (size_t)img.width + xi];
+        const double s = 1.0 / 255.0;
         return mk((double)px.x * s, (double)px.y * s, (double)px.z * s);
     }
-    if (T.kind == RT_TEX_NOISE) { // noise.rs:26-33
-        double f = 1.0 + sin(T.scale * p.z + 10.0 * perlin_turbulence(A.perlins[T.perlin], p, T.depth));
-        return (ld3(T.color) * 0.5) * f;
+    if (kind == RT_TEX_NOISE) { // noise.rs:26-33
+        double turb;
+        if (lds_perlin != nullptr && T->perlin == 0) turb = perlin_turbulence(*lds_perlin, p, T->depth);
+        else turb = perlin_turbulence_global(&A.perlins[T->perlin], p, T->depth);
+        const double f = 1.0 + sin_lean(T->scale * p.z + 10.0 * turb);
+        return (ld3(T->color) * 0.5) * f;
     }
-    return ld3(T.color);
+    return ld3(T->color);
 }
 
 template <bool TEXTURED>
-__device__ __forceinline__ d3 texture_value(const TraceArgs &A, const Material &M, double u, double v, d3 p) {
+__device__ __forceinline__ d3 texture_value(const TraceArgs &A, const Perlin *lds_perlin, const Material &M, double u,
+                                            double v, d3 p) {
     if (!TEXTURED || M.tex_kind == RT_TEX_SOLID_COLOR) return ld3(M.color); // solid_color.rs:24-28
-    return texture_value_slow(A, M.texture, u, v, p);
+    return texture_value_full(A, lds_perlin, M.texture, u, v, p);
 }
 
 } // namespace rtdev

@@ -32,6 +32,7 @@
 //    accepted candidate in stream order.  ~3 rounds instead of ~6.4, identical
 //    values (the accepted candidate is exactly the one the sequential loop
 //    would have stopped at).
+#include <type_traits>
 #include "rt_trace_common.h"
 
 namespace rtdev {
@@ -89,8 +90,22 @@ __device__ __forceinline__ d3 coop_random_in_unit_sphere(bool need, uint32_t pix
 }
 
 template <int PRIMS, bool TEXTURED, bool SPECULAR>
-__global__ __launch_bounds__(256) void k_trace_pool_f64(const TraceArgs A) {
+__global__ __launch_bounds__(256, TEXTURED ? 3 : 5) void k_trace_pool_f64(const TraceArgs A) {
     __shared__ WaveLds lds_all[4];
+    // The first Perlin table (9 KB: 256 gradients + permutations) is staged in LDS
+    // once per block; the 56 random gradient fetches of a marble lookup then hit
+    // LDS instead of the vector memory path.
+    __shared__ typename std::conditional<TEXTURED, Perlin, int>::type lds_perlin_storage;
+    const Perlin *lds_perlin = nullptr;
+    if (TEXTURED) {
+        if (A.n_perlins > 0) {
+            const uint64_t *src = reinterpret_cast<const uint64_t *>(A.perlins);
+            uint64_t *dst = reinterpret_cast<uint64_t *>(&lds_perlin_storage);
+            for (int i = threadIdx.x; i < (int)(sizeof(Perlin) / 8); i += 256) dst[i] = src[i];
+            lds_perlin = reinterpret_cast<const Perlin *>(&lds_perlin_storage);
+        }
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     WaveLds &L = lds_all[threadIdx.x >> 6];
     unsigned int n_segments = 0;
@@ -233,14 +248,14 @@ __global__ __launch_bounds__(256) void k_trace_pool_f64(const TraceArgs A) {
                         h = prim_hit_record<PRIMS, TEXTURED>(P, o, d, best_t, best_aux, M.needs_uv != 0);
                         const int kind = M.kind;
                         if (kind == RT_MAT_DIFFUSE_LIGHT) { // diffuse_light.rs:25-37
-                            contrib = T * texture_value<TEXTURED>(A, M, h.u, h.v, h.point);
+                            contrib = T * texture_value<TEXTURED>(A, lds_perlin, M, h.u, h.v, h.point);
                             ended = true;
                         } else if (kind == RT_MAT_LAMBERTIAN) { // lambertian.rs:26-38 (direction below)
-                            albedo = texture_value<TEXTURED>(A, M, h.u, h.v, h.point);
+                            albedo = texture_value<TEXTURED>(A, lds_perlin, M, h.u, h.v, h.point);
                             is_lambert = true;
                             need_sphere = true;
                         } else if (SPECULAR && kind == RT_MAT_METAL) { // metal.rs:26-43 (fuzz below)
-                            albedo = texture_value<TEXTURED>(A, M, h.u, h.v, h.point);
+                            albedo = texture_value<TEXTURED>(A, lds_perlin, M, h.u, h.v, h.point);
                             fuzz = M.fuzz;
                             is_metal = true;
                             need_sphere = fuzz != 0.0; // fuzz 0 multiplies the sample by 0: its draws are dead
