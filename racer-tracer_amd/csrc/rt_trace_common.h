@@ -77,14 +77,20 @@ struct u4 {
     uint32_t a, b, c, d;
 };
 
+// gfx950's three-input bitwise op (truth table 0x96 = a ^ b ^ c) folds the two
+// xors of every Philox half-round into one VALU instruction.
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
+
 __device__ __forceinline__ u4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                             uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         uint64_t p0 = (uint64_t)RT_PHILOX_M0 * c0;
         uint64_t p1 = (uint64_t)RT_PHILOX_M1 * c2;
-        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
+        uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, k1);
         c1 = (uint32_t)p1;
         c3 = (uint32_t)p0;
         c0 = n0;
@@ -102,6 +108,15 @@ __device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
     return fma((double)top, 0x1p-21, (double)low * 0x1p-53);
 }
 
+// random_double_range(-1, 1) of the same draw: -1 + 2 * u53(hi, lo).  Every
+// intermediate is exactly representable (multiples of 2^-52 below 1 in
+// magnitude), so this equals the oracle's a + (b - a) * d bit for bit.
+__device__ __forceinline__ double sym53(uint32_t hi, uint32_t lo) {
+    uint32_t top = hi >> 11;
+    uint32_t low = (hi << 21) | (lo >> 11);
+    return fma((double)top, 0x1p-20, fma((double)low, 0x1p-52, -1.0));
+}
+
 struct PathRng {
     uint32_t pixel, sample, k0, k1;
     __device__ __forceinline__ u4 block(uint32_t segment, uint32_t purpose, uint32_t blk) const {
@@ -114,8 +129,8 @@ __device__ __forceinline__ d3 random_in_unit_sphere(const PathRng &rng, uint32_t
     for (uint32_t i = 0;; ++i) {
         u4 b0 = rng.block(segment, RT_RNG_SCATTER, 2 * i);
         u4 b1 = rng.block(segment, RT_RNG_SCATTER, 2 * i + 1);
-        d3 p = mk(fma(2.0, u53(b0.a, b0.b), -1.0), fma(2.0, u53(b0.c, b0.d), -1.0),
-                  fma(2.0, u53(b1.a, b1.b), -1.0));
+        d3 p = mk(sym53(b0.a, b0.b), sym53(b0.c, b0.d),
+                  sym53(b1.a, b1.b));
         if (len2(p) >= 1.0) continue;
         return p;
     }

@@ -62,8 +62,8 @@ __global__ __launch_bounds__(256) void k_trace_f64(const TraceArgs A) {
                 double rx, ry;
                 for (uint32_t i = 0;; ++i) { // util.rs:25-39
                     u4 b = rng.block(0, RT_RNG_LENS, i);
-                    rx = fma(2.0, u53(b.a, b.b), -1.0);
-                    ry = fma(2.0, u53(b.c, b.d), -1.0);
+                    rx = sym53(b.a, b.b);
+                    ry = sym53(b.c, b.d);
                     if (rx * rx + ry * ry >= 1.0) continue;
                     break;
                 }

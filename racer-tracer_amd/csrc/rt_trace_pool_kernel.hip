@@ -68,8 +68,8 @@ __device__ __forceinline__ d3 coop_random_in_unit_sphere(bool need, uint32_t pix
         const uint32_t i = r.w + (uint32_t)c;  // candidate index: blocks 2i and 2i+1 (rt_rng.h)
         const u4 b0 = philox4x32_10(r.x, r.y, (r.z << 8) | RT_RNG_SCATTER, 2u * i, k0, k1);
         const u4 b1 = philox4x32_10(r.x, r.y, (r.z << 8) | RT_RNG_SCATTER, 2u * i + 1u, k0, k1);
-        const d3 p = mk(fma(2.0, u53(b0.a, b0.b), -1.0), fma(2.0, u53(b0.c, b0.d), -1.0),
-                        fma(2.0, u53(b1.a, b1.b), -1.0));
+        const d3 p = mk(sym53(b0.a, b0.b), sym53(b0.c, b0.d),
+                        sym53(b1.a, b1.b));
         const uint64_t accepted = __ballot(serving && len2(p) < 1.0);
         // first accepted candidate of my own request, in stream order
         const int first = need ? (rank << lg) : 0;
@@ -183,8 +183,8 @@ __global__ __launch_bounds__(256, TEXTURED ? 3 : 5) void k_trace_pool_f64(const 
                         double rx, ry;
                         for (uint32_t i = 0;; ++i) { // util.rs:25-39
                             const u4 b = rng.block(0, RT_RNG_LENS, i);
-                            rx = fma(2.0, u53(b.a, b.b), -1.0);
-                            ry = fma(2.0, u53(b.c, b.d), -1.0);
+                            rx = sym53(b.a, b.b);
+                            ry = sym53(b.c, b.d);
                             if (rx * rx + ry * ry >= 1.0) continue;
                             break;
                         }
