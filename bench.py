@@ -83,6 +83,19 @@ def cpu_baseline(session, seconds):
                       % (p.width, p.height, spp, dt, segs / n)}
 
 
+def pmc_traffic(workload, spp, world):
+    """HBM bytes per launch of the trace kernel, from the committed PMC summary
+    of the SAME workload (profiles/pmc_traffic.json, produced by
+    tools/gpu_pmc.sh + tools/pmc_to_traffic.py).  None when there is no
+    measurement for this exact configuration."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if world != 1 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        table = json.load(f)
+    return table.get("%s:%d" % (workload, spp))
+
+
 def main():
     args = parse()
     import torch
@@ -181,15 +194,24 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None,
-                "kernel": "k_trace_f64",
+                "kernel": "k_trace_pool_f64",
                 "kernel_ms": round(k_ms, 3),
                 "segments_per_launch": seg_per_step / world,
                 "bytes_per_segment": BYTES_PER_SEGMENT_F64,
+                "algorithmic_bytes_per_launch": BYTES_PER_SEGMENT_F64 * seg_per_step / world,
                 "gsegments_per_s": round(seg_per_step / (k_ms * 1e-3) / 1e9, 3),
                 "note": "achieved = algorithmic ray-state bytes (192 B/segment, SURVEY 8d) / kernel time; "
-                        "the kernel keeps ray state in registers, so real HBM traffic is the framebuffer only",
+                        "the kernel keeps ray state in registers, so its real HBM traffic is the per-chunk "
+                        "framebuffer slices only and frac can exceed 1",
             },
         }
+        pmc = pmc_traffic(args.workload, spp, world)
+        if pmc is not None:
+            # HBM bytes of one k_trace_pool_f64 launch from rocprofv3 PMC passes (tools/gpu_pmc.sh),
+            # corrected as MI355X_MICROARCH.md prescribes, over the live kernel duration
+            out["roofline"]["traffic"] = round(pmc["bytes_per_launch"] / (k_ms * 1e-3) / 1e9, 3)
+            out["roofline"]["traffic_bytes_per_launch"] = pmc["bytes_per_launch"]
+            out["roofline"]["traffic_source"] = pmc["source"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(session, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -21,18 +21,26 @@ for counters in "${groups[@]}"; do
     f=$(find "$out" -name '*counter_collection.csv' | sort | sed -n 1p)
     echo "== group $g: $counters"
     if [ -n "$f" ]; then
-        python3 - "$f" <<'EOF'
+        python3 - "$f" "$root/summary.json" <<'EOF'
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+import json
+summary_path = sys.argv[2]
+try:
+    summary = json.load(open(summary_path))
+except Exception:
+    summary = {}
 for k, cs in agg.items():
     if "trace" not in k and "resolve" not in k:
         continue
     print(k)
     for c, v in sorted(cs.items()):
         print("   %-28s n=%d mean=%.6g" % (c, len(v), sum(v) / len(v)))
+        summary.setdefault(k, {})[c] = {"dispatches": len(v), "mean": sum(v) / len(v)}
+json.dump(summary, open(summary_path, "w"), indent=1, sort_keys=True)
 EOF
     else
         echo "no counter_collection.csv"; ls -R "$out" | head
