@@ -49,13 +49,16 @@ struct WaveLds {
 };
 
 // vec3.rs:424-430 for every lane with `need`, evaluated by the whole wave.
-// Must be called by all 64 lanes (wave-uniform control flow).
-__device__ __forceinline__ d3 coop_random_in_unit_sphere(bool need, uint32_t pixel, uint32_t sample, uint32_t seg,
-                                                         uint32_t k0, uint32_t k1, int lane, uint4 *req) {
-    d3 result = mk(0.0, 0.0, 0.0);
-    uint32_t base = 0; // first untested candidate of this lane's request
+// Must be called by all 64 lanes (wave-uniform control flow).  Runs at most
+// `max_rounds` rounds: a lane whose request is still open afterwards returns
+// false and keeps `base` (its first untested candidate), so the search resumes
+// at the same stream position in the next call.
+__device__ __forceinline__ bool coop_random_in_unit_sphere(bool need, uint32_t pixel, uint32_t sample, uint32_t seg,
+                                                           uint32_t &base, uint32_t k0, uint32_t k1, int lane,
+                                                           uint4 *req, int max_rounds, d3 &result) {
+    bool have = false;
     uint64_t pending = __ballot(need);
-    while (pending != 0) {
+    for (int round = 0; round < max_rounds && pending != 0; ++round) {
         const int n = __popcll(pending);
         // group size q = 2^lg, the largest power of two with n * q <= 64
         const int lg = n > 32 ? 0 : (n > 16 ? 1 : (n > 8 ? 2 : (n > 4 ? 3 : (n > 2 ? 4 : (n > 1 ? 5 : 6)))));
@@ -68,8 +71,7 @@ __device__ __forceinline__ d3 coop_random_in_unit_sphere(bool need, uint32_t pix
         const uint32_t i = r.w + (uint32_t)c;  // candidate index: blocks 2i and 2i+1 (rt_rng.h)
         const u4 b0 = philox4x32_10(r.x, r.y, (r.z << 8) | RT_RNG_SCATTER, 2u * i, k0, k1);
         const u4 b1 = philox4x32_10(r.x, r.y, (r.z << 8) | RT_RNG_SCATTER, 2u * i + 1u, k0, k1);
-        const d3 p = mk(sym53(b0.a, b0.b), sym53(b0.c, b0.d),
-                        sym53(b1.a, b1.b));
+        const d3 p = mk(sym53(b0.a, b0.b), sym53(b0.c, b0.d), sym53(b1.a, b1.b));
         const uint64_t accepted = __ballot(serving && len2(p) < 1.0);
         // first accepted candidate of my own request, in stream order
         const int first = need ? (rank << lg) : 0;
@@ -81,12 +83,13 @@ __device__ __forceinline__ d3 coop_random_in_unit_sphere(bool need, uint32_t pix
         if (got) {
             result = mk(rx, ry, rz);
             need = false;
+            have = true;
         } else if (need) {
             base += 1u << lg;
         }
         pending = __ballot(need);
     }
-    return result;
+    return have;
 }
 
 template <int PRIMS, bool TEXTURED, bool SPECULAR>
@@ -151,6 +154,14 @@ __global__ __launch_bounds__(256, TEXTURED ? 3 : 5) void k_trace_pool_f64(const 
         PathRng rng{0, 0, A.seed_lo, A.seed_hi};
         d3 o = mk(0, 0, 0), d = o, T = o;
         uint32_t seg = 0;
+        // A lane whose hit needs a random_in_unit_sphere sample that the wave has not
+        // found yet stays `waiting` (it keeps its hit below and skips tracing) until a
+        // later iteration's sampler rounds reach its accepted candidate.
+        bool waiting = false;
+        uint32_t cand_base = 0;   // first untested candidate of the open request
+        bool is_lambert = false;  // material of the open hit (else Metal)
+        d3 hit_point = o, hit_normal = o, albedo = o;
+        double fuzz = 0.0;
 
         for (;;) {
             // ---- hand pool entries to the lanes without a path (ballot + prefix count)
@@ -206,16 +217,9 @@ __global__ __launch_bounds__(256, TEXTURED ? 3 : 5) void k_trace_pool_f64(const 
             // ---- one ray_color level for every lane with a path
             d3 contrib = mk(0.0, 0.0, 0.0); // what the path adds to its pixel if it ends here
             bool ended = false;
-            bool need_sphere = false;       // wants a random_in_unit_sphere sample
-            bool is_lambert = false, is_metal = false;
-            Hit h;
-            h.point = o;
-            h.normal = o;
-            h.u = h.v = 0.0;
-            h.front = true;
-            d3 albedo = mk(0.0, 0.0, 0.0);
-            double fuzz = 0.0;
-            if (alive) {
+            bool scattered = false;  // the path got a new ray this iteration (depth check below)
+            bool finish = false;     // Lambertian / Metal hit whose direction can be completed now
+            if (alive && !waiting) {
                 if (A.max_depth <= 0) { // renderer.rs:48-55 with max_depth 0
                     contrib = T;
                     ended = true;
@@ -245,20 +249,27 @@ __global__ __launch_bounds__(256, TEXTURED ? 3 : 5) void k_trace_pool_f64(const 
                     } else {
                         const Prim &P = A.prims[best];
                         const Material &M = A.materials[P.material];
-                        h = prim_hit_record<PRIMS, TEXTURED>(P, o, d, best_t, best_aux, M.needs_uv != 0);
+                        const Hit h = prim_hit_record<PRIMS, TEXTURED>(P, o, d, best_t, best_aux, M.needs_uv != 0);
                         const int kind = M.kind;
                         if (kind == RT_MAT_DIFFUSE_LIGHT) { // diffuse_light.rs:25-37
                             contrib = T * texture_value<TEXTURED>(A, lds_perlin, M, h.u, h.v, h.point);
                             ended = true;
                         } else if (kind == RT_MAT_LAMBERTIAN) { // lambertian.rs:26-38 (direction below)
                             albedo = texture_value<TEXTURED>(A, lds_perlin, M, h.u, h.v, h.point);
+                            hit_point = h.point;
+                            hit_normal = h.normal;
                             is_lambert = true;
-                            need_sphere = true;
+                            waiting = true;
+                            cand_base = 0;
                         } else if (SPECULAR && kind == RT_MAT_METAL) { // metal.rs:26-43 (fuzz below)
                             albedo = texture_value<TEXTURED>(A, lds_perlin, M, h.u, h.v, h.point);
+                            hit_point = h.point;
+                            hit_normal = h.normal;
                             fuzz = M.fuzz;
-                            is_metal = true;
-                            need_sphere = fuzz != 0.0; // fuzz 0 multiplies the sample by 0: its draws are dead
+                            is_lambert = false;
+                            cand_base = 0;
+                            waiting = fuzz != 0.0; // fuzz 0 multiplies the sample by 0: its draws are dead
+                            finish = !waiting;
                         } else if (SPECULAR) { // dialectric.rs:25-55
                             const double ratio = h.front ? 1.0 / M.ior : M.ior;
                             const d3 ud = unit_fast(d);
@@ -281,6 +292,7 @@ __global__ __launch_bounds__(256, TEXTURED ? 3 : 5) void k_trace_pool_f64(const 
                                 d = perp + (-sqrt(fabs(1.0 - len2(perp)))) * h.normal;
                             }
                             o = h.point;
+                            scattered = true;
                         } else { // unreachable: the host picks SPECULAR whenever such a material exists
                             ended = true;
                         }
@@ -288,35 +300,43 @@ __global__ __launch_bounds__(256, TEXTURED ? 3 : 5) void k_trace_pool_f64(const 
                 }
             }
 
-            // ---- the wave evaluates the rejection loops together (all 64 lanes arrive here)
-            const d3 sph = coop_random_in_unit_sphere(need_sphere, rng.pixel, rng.sample, seg, A.seed_lo, A.seed_hi,
-                                                      lane, L.req);
+            // ---- the wave evaluates the open rejection loops together (all 64 lanes arrive
+            // here): two rounds settle ~90 % of the requests; the rest resume next iteration,
+            // which costs them one idle pass instead of costing the wave a third round
+            d3 sph = mk(0.0, 0.0, 0.0);
+            if (coop_random_in_unit_sphere(waiting, rng.pixel, rng.sample, seg, cand_base, A.seed_lo, A.seed_hi, lane,
+                                           L.req, 2, sph)) {
+                waiting = false;
+                finish = true;
+            }
 
-            if (alive && !ended) {
+            if (finish) {
                 if (is_lambert) { // lambertian.rs:27-33
-                    d3 dir = h.normal + unit_fast(sph);
-                    if (fabs(dir.x) < 1e-8 && fabs(dir.y) < 1e-8 && fabs(dir.z) < 1e-8) dir = h.normal;
+                    d3 dir = hit_normal + unit_fast(sph);
+                    if (fabs(dir.x) < 1e-8 && fabs(dir.y) < 1e-8 && fabs(dir.z) < 1e-8) dir = hit_normal;
                     T = T * albedo;
-                    o = h.point;
+                    o = hit_point;
                     d = dir;
-                } else if (SPECULAR && is_metal) { // metal.rs:30-42
+                    scattered = true;
+                } else if (SPECULAR) { // metal.rs:30-42
                     const d3 ud = unit_fast(d);
-                    d3 dir = ud - (2.0 * dot(ud, h.normal)) * h.normal;
-                    if (need_sphere) dir = dir + fuzz * sph;
-                    if (dot(dir, h.normal) < 0.0) {
+                    d3 dir = ud - (2.0 * dot(ud, hit_normal)) * hit_normal;
+                    if (fuzz != 0.0) dir = dir + fuzz * sph;
+                    if (dot(dir, hit_normal) < 0.0) {
                         contrib = mk(0.0, 0.0, 0.0);
                         ended = true;
                     } else {
                         T = T * albedo;
-                        o = h.point;
+                        o = hit_point;
                         d = dir;
+                        scattered = true;
                     }
                 }
-                // renderer.rs:48-55: the recursion's next level has depth 0 -> white
-                if (!ended && (int)++seg >= A.max_depth) {
-                    contrib = T;
-                    ended = true;
-                }
+            }
+            // renderer.rs:48-55: the recursion's next level has depth 0 -> white
+            if (scattered && (int)++seg >= A.max_depth) {
+                contrib = T;
+                ended = true;
             }
             if (alive && ended) { // vec3.rs:38-42 Color::add into the pixel's sum
                 atomicAdd(&L.sum[pix][0], contrib.x);
