@@ -109,11 +109,20 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: there is no CPU fallback for the render path")
+    # BENCH_REHEARSE_ON_ONE_GPU=1: every rank uses device 0 and the collective goes
+    # over gloo (RCCL cannot put several ranks on one card).  A functional rehearsal of
+    # the N > 1 path for a 1-GPU box; its numbers mean nothing.
+    rehearsal = os.environ.get("BENCH_REHEARSE_ON_ONE_GPU") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     rt = importlib.import_module("racer-tracer_amd")
     host = importlib.import_module("racer-tracer_amd.host")
@@ -152,13 +161,14 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        red_dev = "cpu" if rehearsal else "cuda"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        seg_t = torch.tensor([float(sum(segments))], dtype=torch.float64, device="cuda")
+        seg_t = torch.tensor([float(sum(segments))], dtype=torch.float64, device=red_dev)
         dist.all_reduce(seg_t, op=dist.ReduceOp.SUM)
         total_segments = float(seg_t.item())
-        k_t = torch.tensor([sum(kernel_ms)], dtype=torch.float64, device="cuda")
+        k_t = torch.tensor([sum(kernel_ms)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(k_t, op=dist.ReduceOp.MAX)
         kernel_total_ms = float(k_t.item())
     else:
@@ -214,6 +224,14 @@ def main():
             out["roofline"]["traffic_source"] = pmc["source"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(session, args.cpu_seconds)
+        if rehearsal:
+            out["rehearsal"] = "N ranks on ONE GPU over gloo: functional check only"
+            # the gathered frame must equal a single-rank render of the same frame
+            p.strip_count = 0
+            whole = torch.zeros_like(frame)
+            scene.render_frame_device(session.camera, p, whole.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+            out["rehearsal_frame_matches_single_rank"] = bool(torch.equal(whole, frame))
         print(json.dumps(out), flush=True)
     scene.close()
     if dist is not None:

@@ -248,18 +248,21 @@ int enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, 
                                     a.strip_index, p->samples, stream));
         RT_HIP(hipEventRecord(s->ev_resolved, stream));
     } else {
-        // Work items = 8x8 tiles x sample chunks.  Chunks per batch: enough items
-        // that the end-of-launch tail is a small fraction (>= 16 items per resident
-        // wave), at least 16 samples each, at most 64 slices of `partial`.
+        // Work items = 8x8 tiles x sample chunks.  The chunk length depends on the
+        // sample count ONLY (never on tiling, strips or the device), because the
+        // chunk boundaries fix the order in which a pixel's samples are summed: the
+        // frame is then bit-identical for every GPU count.  32 samples per chunk
+        // measured best over 16..512 on cornell_box / three_balls (items stay short
+        // enough for a small end-of-launch tail at 1/8 of a frame per GPU, long
+        // enough that an item's own ramp-down is small); at most 64 slices.
         a.tiles_x = (p->width + 7) / 8;
         a.n_tiles = a.tiles_x * ((a.owned_rows + 7) / 8);
-        const long long resident_waves = (long long)s->num_cus * s->pool_blocks_per_cu * 4;
-        int want = a.n_tiles > 0 ? (int)((16 * resident_waves + a.n_tiles - 1) / a.n_tiles) : 1;
-        if (want < batch / 128) want = batch / 128;
-        if (want > batch / 16) want = batch / 16;
-        if (want > 64 / n_batches) want = 64 / n_batches;
-        if (want < 1) want = 1;
-        const int chunk_samples = (batch + want - 1) / want;
+        int chunk_samples = 32;
+        const int max_slices = 64 / n_batches > 0 ? 64 / n_batches : 1;
+        if ((batch + chunk_samples - 1) / chunk_samples > max_slices) chunk_samples = (batch + max_slices - 1) / max_slices;
+        if (chunk_samples > batch) chunk_samples = batch;
+        if (const char *k = getenv("RT_POOL_CHUNK")) // developer knob
+            if (atoi(k) > 0) chunk_samples = atoi(k) < batch ? atoi(k) : batch;
         const int chunks_per_batch = (batch + chunk_samples - 1) / chunk_samples;
         const int total_chunks = chunks_per_batch * n_batches;
         if (s->partial.count < n * (size_t)total_chunks) RT_HIP(s->partial.alloc(n * (size_t)total_chunks));

@@ -44,7 +44,17 @@ class StripGather:
         strips = self.padded.view(self.n_strips, self.rows, self.w, 3)
         mine = strips[self.rank :: self.world]
         self.send[: mine.shape[0]].copy_(mine)
-        self.dist.gather(self.send, self.recv, dst=0)
+        if self.send.is_cuda and self.dist.get_backend() == "gloo":
+            # functional rehearsal of the N > 1 path on one GPU (several ranks share the
+            # card, RCCL cannot): stage the collective through host memory
+            send = self.send.cpu()
+            recv = [torch.zeros_like(send) for _ in range(self.world)] if self.rank == 0 else None
+            self.dist.gather(send, recv, dst=0)
+            if self.rank == 0:
+                for r in range(self.world):
+                    self.recv[r].copy_(recv[r])
+        else:
+            self.dist.gather(self.send, self.recv, dst=0)
         if self.rank == 0:
             for r in range(self.world):
                 k = len(self.owned(r))

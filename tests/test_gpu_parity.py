@@ -92,11 +92,13 @@ def test_strips_assemble_to_full_frame(rt, orc, gpu):
     """Multi-GPU row ownership: N strip renders == one full render, bit for bit
     (the RNG is keyed by the global pixel index)."""
     bundle, cam, _ = S.cornell_box()
-    w, h, spp = 96, 70, 8
+    w, h, spp = 96, 70, 72   # 72 spp = three sample chunks: the per-chunk sums must not depend on the strip layout
     camera = S.camera_for(cam, w, h)
     scene = rt.Scene(bundle)
     try:
         full = scene.render_frame(camera, S.abi.render_params(w, h, spp))
+        again = scene.render_frame(camera, S.abi.render_params(w, h, spp))
+        assert np.array_equal(full, again)   # LDS accumulation order is fixed within an item
         for count, rows in ((2, 8), (3, 8), (8, 8), (4, 16)):
             acc = np.full_like(full, -1.0)
             for idx in range(count):
