@@ -205,6 +205,8 @@ void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtd
     }
     a.seed_lo = (uint32_t)(p->seed & 0xffffffffull);
     a.seed_hi = (uint32_t)(p->seed >> 32);
+    a.inv_width_m1 = 1.0 / (double)(p->width - 1);
+    a.inv_height_m1 = 1.0 / (double)(p->height - 1);
     for (int k = 0; k < 3; ++k) {
         a.cam.origin[k] = c->origin[k];
         a.cam.ulc[k] = c->upper_left_corner[k];

@@ -96,6 +96,8 @@ struct TraceArgs {
     int32_t chunk_base;          // index of this launch's first chunk in `partial`
     int32_t chunk_samples;       // samples per chunk (the last one may be shorter)
     int32_t tiles_x, n_tiles;    // 8x8 tiles over width x owned_rows
+    // cpu.rs:36,40 divide by (W-1) and (H-1); the pooled kernel multiplies by these
+    double inv_width_m1, inv_height_m1;
 };
 
 } // namespace rtdev

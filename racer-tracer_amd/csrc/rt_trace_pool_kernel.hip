@@ -92,6 +92,43 @@ __device__ __forceinline__ bool coop_random_in_unit_sphere(bool need, uint32_t p
     return have;
 }
 
+// util.rs:25-39 random_in_unit_disk for every lane with `need`, same scheme: one
+// Philox block per candidate (block i -> x, y), first accepted candidate in stream
+// order.  Runs until every request is settled (a fresh path needs its ray now).
+__device__ __forceinline__ void coop_random_in_unit_disk(bool need, uint32_t pixel, uint32_t sample, uint32_t k0,
+                                                         uint32_t k1, int lane, uint4 *req, double &out_x,
+                                                         double &out_y) {
+    uint32_t base = 0;
+    uint64_t pending = __ballot(need);
+    while (pending != 0) {
+        const int n = __popcll(pending);
+        const int lg = n > 32 ? 0 : (n > 16 ? 1 : (n > 8 ? 2 : (n > 4 ? 3 : (n > 2 ? 4 : (n > 1 ? 5 : 6)))));
+        const int rank = lane_rank(pending);
+        if (need) req[rank] = make_uint4(pixel, sample, 0u, base);
+        const int j = lane >> lg;
+        const int c = lane & ((1 << lg) - 1);
+        const bool serving = j < n;
+        const uint4 r = req[serving ? j : 0];
+        const u4 b = philox4x32_10(r.x, r.y, RT_RNG_LENS, r.w + (uint32_t)c, k0, k1);
+        const double x = sym53(b.a, b.b), y = sym53(b.c, b.d);
+        const uint64_t accepted = __ballot(serving && x * x + y * y < 1.0);
+        const int first = need ? (rank << lg) : 0;
+        const uint64_t width_mask = lg == 6 ? ~0ull : ((1ull << (1 << lg)) - 1ull);
+        const uint64_t mine = need ? ((accepted >> first) & width_mask) : 0ull;
+        const bool got = mine != 0;
+        const int src = got ? first + __ffsll((unsigned long long)mine) - 1 : lane;
+        const double rx = __shfl(x, src, 64), ry = __shfl(y, src, 64);
+        if (got) {
+            out_x = rx;
+            out_y = ry;
+            need = false;
+        } else if (need) {
+            base += 1u << lg;
+        }
+        pending = __ballot(need);
+    }
+}
+
 template <int PRIMS, bool TEXTURED, bool SPECULAR>
 __global__ __launch_bounds__(256, TEXTURED ? 3 : 5) void k_trace_pool_f64(const TraceArgs A) {
     __shared__ WaveLds lds_all[4];
@@ -139,7 +176,7 @@ __global__ __launch_bounds__(256, TEXTURED ? 3 : 5) void k_trace_pool_f64(const 
         {
             PathRng prng{my_pixel, RT_RNG_SAMPLE_PIXEL, A.seed_lo, A.seed_hi};
             u4 bj = prng.block(0, RT_RNG_PIXEL, 0);
-            L.u[lane] = ((double)my_px + u53(bj.a, bj.b)) / (double)(A.width - 1); // cpu.rs:35-36
+            L.u[lane] = ((double)my_px + u53(bj.a, bj.b)) * A.inv_width_m1; // cpu.rs:35-36
             L.sum[lane][0] = 0.0;
             L.sum[lane][1] = 0.0;
             L.sum[lane][2] = 0.0;
@@ -165,6 +202,8 @@ __global__ __launch_bounds__(256, TEXTURED ? 3 : 5) void k_trace_pool_f64(const 
 
         for (;;) {
             // ---- hand pool entries to the lanes without a path (ballot + prefix count)
+            bool fresh = false; // this lane starts a new path in this iteration
+            int py = 0;
             if (next < total) {
                 const uint64_t idle = __ballot(!alive);
                 const uint32_t w = next + (uint32_t)lane_rank(idle);
@@ -180,37 +219,31 @@ __global__ __launch_bounds__(256, TEXTURED ? 3 : 5) void k_trace_pool_f64(const 
                     }
                     const int px = tx * 8 + (pix & 7);
                     const int vrow = ty * 8 + (pix >> 3);
-                    int py = vrow;
+                    py = vrow;
                     if (A.strip_count > 1)
                         py = ((vrow / A.strip_rows) * A.strip_count + A.strip_index) * A.strip_rows + vrow % A.strip_rows;
                     rng.pixel = (uint32_t)py * (uint32_t)A.width + (uint32_t)px;
                     rng.sample = (uint32_t)(smp0 + s_off);
-                    // cpu.rs:39-40 + camera.rs:326-337
-                    const u4 bc = rng.block(0, RT_RNG_CAMERA, 0);
-                    const double v = ((double)py + u53(bc.a, bc.b)) / (double)(A.height - 1);
-                    const double u = L.u[pix];
-                    d3 offset = mk(0.0, 0.0, 0.0);
-                    if (A.cam.lens_radius != 0.0) { // aperture 0: the disk is multiplied by 0 -> its draws are dead
-                        double rx, ry;
-                        for (uint32_t i = 0;; ++i) { // util.rs:25-39
-                            const u4 b = rng.block(0, RT_RNG_LENS, i);
-                            rx = sym53(b.a, b.b);
-                            ry = sym53(b.c, b.d);
-                            if (rx * rx + ry * ry >= 1.0) continue;
-                            break;
-                        }
-                        rx *= A.cam.lens_radius;
-                        ry *= A.cam.lens_radius;
-                        offset = ld3(A.cam.right) * rx + ld3(A.cam.up) * ry;
-                    }
-                    const d3 co = ld3(A.cam.origin);
-                    o = co + offset;
-                    d = ld3(A.cam.ulc) + u * ld3(A.cam.horizontal) - v * ld3(A.cam.vertical) - co - offset;
-                    // (ray time, camera.rs:335, is drawn by the oracle; nothing in scope reads it)
-                    T = mk(1.0, 1.0, 1.0);
-                    seg = 0;
-                    alive = true;
+                    fresh = true;
                 }
+            }
+            // camera.rs:327: the lens disk of the fresh paths, sampled by the whole wave.
+            // Aperture 0 multiplies the disk by 0, so its draws are dead and skipped.
+            double lens_x = 0.0, lens_y = 0.0;
+            if (A.cam.lens_radius != 0.0)
+                coop_random_in_unit_disk(fresh, rng.pixel, rng.sample, A.seed_lo, A.seed_hi, lane, L.req, lens_x, lens_y);
+            if (fresh) { // cpu.rs:39-40 + camera.rs:326-337
+                const u4 bc = rng.block(0, RT_RNG_CAMERA, 0);
+                const double v = ((double)py + u53(bc.a, bc.b)) * A.inv_height_m1;
+                const double u = L.u[pix];
+                const d3 offset = ld3(A.cam.right) * (lens_x * A.cam.lens_radius) + ld3(A.cam.up) * (lens_y * A.cam.lens_radius);
+                const d3 co = ld3(A.cam.origin);
+                o = co + offset;
+                d = ld3(A.cam.ulc) + u * ld3(A.cam.horizontal) - v * ld3(A.cam.vertical) - co - offset;
+                // (ray time, camera.rs:335, is drawn by the oracle; nothing in scope reads it)
+                T = mk(1.0, 1.0, 1.0);
+                seg = 0;
+                alive = true;
             }
             if (__ballot(alive) == 0) break; // pool dry and nothing in flight
 
