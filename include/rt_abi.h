@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 /* ------------------------------------------------------------------ errors
  * 0 = Ok.  1..22 are exactly the reference's exit codes
@@ -122,7 +122,9 @@ enum RtPrimitiveKind {
     RT_PRIM_XY_RECT = 1, /* geometry/xy_rect.rs : p = x0, x1, y0, y1, k         */
     RT_PRIM_XZ_RECT = 2, /* geometry/xz_rect.rs : p = x0, x1, z0, z1, k         */
     RT_PRIM_YZ_RECT = 3, /* geometry/yz_rect.rs : p = y0, y1, z0, z1, k         */
-    RT_PRIM_BOX = 4      /* geometry/box.rs     : p = min xyz, max xyz          */
+    RT_PRIM_BOX = 4,     /* geometry/box.rs     : p = min xyz, max xyz          */
+    RT_PRIM_MOVING_SPHERE = 5 /* geometry/moving_sphere.rs : p = cx, cy, cz (at time_a), radius;
+                                 center_b = centre at time_b; linear in ray.time()      */
 };
 
 enum RtPrimitiveFlags {
@@ -139,6 +141,9 @@ typedef struct RtPrimitive {
     double rot_sin;      /* sin/cos of radians(degrees), rotate_y.rs:19-28 */
     double rot_cos;
     double translate[3]; /* translate.rs:13-16 */
+    double center_b[3];  /* MovingSphere.pos_b (moving_sphere.rs:20-25) */
+    double time_a;       /* MovingSphere.time_a / time_b: 0 and 1 in the reference */
+    double time_b;       /*   (scene/random.rs:55)                                 */
 } RtPrimitive;
 
 /* -------------------------------------------------------------- background

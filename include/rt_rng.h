@@ -51,6 +51,10 @@
 #define RT_RNG_BVH 6        /* oracle only: pixel = build-node index; axis = d0 < 0.5 ? 0 : 1 */
                             /* (bvh_node.rs:32: random_int_range(0,2))                        */
 
+#define RT_RNG_SCENE 7      /* host: the procedural `random` scene (scene/random.rs:39-70):   */
+                            /* pixel = n for the loader's n-th random_double(), sample =      */
+                            /* RT_RNG_SAMPLE_TABLE, segment 0, block 0: d0                     */
+
 /* Philox4x32-10 constants (Salmon et al., SC'11). */
 #define RT_PHILOX_M0 0xD2511F53u
 #define RT_PHILOX_M1 0xCD9E8D57u

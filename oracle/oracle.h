@@ -68,6 +68,9 @@ typedef struct OrcHit {
 /* One primitive incl. its RotateY/Translate wrappers; returns 1 on hit. */
 int orc_hit_primitive(const RtPrimitive *prim, const double origin[3], const double dir[3],
                       double t_min, double t_max, OrcHit *out);
+/* ... with the ray's time (ray.rs:26-28), which only MovingSphere reads */
+int orc_hit_primitive_time(const RtPrimitive *prim, const double origin[3], const double dir[3], double time,
+                           double t_min, double t_max, OrcHit *out);
 /* AABB of a primitive incl. wrappers, as geometry_creation.rs builds it
  * (RotateY's box reproduces rotate_y.rs:66-90 bit for bit, bugs included). */
 void orc_primitive_aabb(const RtPrimitive *prim, double out_min[3], double out_max[3]);
@@ -82,6 +85,8 @@ OrcScene *orc_scene_build(const RtSceneDesc *desc, int use_bvh, uint64_t seed);
 void orc_scene_free(OrcScene *s);
 int orc_scene_hit(const OrcScene *s, const double origin[3], const double dir[3],
                   double t_min, double t_max, OrcHit *out);
+int orc_scene_hit_time(const OrcScene *s, const double origin[3], const double dir[3], double time,
+                       double t_min, double t_max, OrcHit *out);
 
 /* ---- textures / background ---- */
 void orc_texture_value(const RtSceneDesc *desc, int32_t texture, double u, double v,

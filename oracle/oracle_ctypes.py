@@ -51,6 +51,8 @@ _PROTOS = {
     "orc_sphere_uv": (None, [_PD, _PD, _PD]),
     "orc_camera_new": (None, [_PD, _PD, _PD, _D, _D, _D, _D, _D, _D, _P(abi.RtCamera)]),
     "orc_hit_primitive": (C.c_int, [_P(abi.RtPrimitive), _PD, _PD, _D, _D, _P(OrcHit)]),
+    "orc_hit_primitive_time": (C.c_int, [_P(abi.RtPrimitive), _PD, _PD, _D, _D, _D, _P(OrcHit)]),
+    "orc_scene_hit_time": (C.c_int, [C.c_void_p, _PD, _PD, _D, _D, _D, _P(OrcHit)]),
     "orc_primitive_aabb": (None, [_P(abi.RtPrimitive), _PD, _PD]),
     "orc_aabb_hit": (C.c_int, [_PD, _PD, _PD, _PD, _D, _D]),
     "orc_scene_build": (C.c_void_p, [_P(abi.RtSceneDesc), C.c_int, C.c_uint64]),

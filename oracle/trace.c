@@ -216,8 +216,39 @@ static int hit_box(const double *p, V3 o, V3 d, double t_min, double t_max, OrcH
     return any;
 }
 
-static int hit_bare(const RtPrimitive *prim, V3 o, V3 d, double t_min, double t_max, OrcHit *h) {
+/* moving_sphere.rs:41-87: the centre moves linearly with the ray's time; uv
+ * comes from the hit POINT, not the normal (moving_sphere.rs:76, SURVEY B-19) */
+static int hit_moving_sphere(const RtPrimitive *prim, V3 o, V3 d, double time, double t_min, double t_max, OrcHit *h) {
+    V3 pos_a = v3(prim->p[0], prim->p[1], prim->p[2]);
+    double radius = prim->p[3];
+    /* moving_sphere.rs:37-39 */
+    V3 center = add(pos_a, scale(sub(v3p(prim->center_b), pos_a), (time - prim->time_a) / (prim->time_b - prim->time_a)));
+    V3 oc = sub(o, center);
+    double a = length_squared(d);
+    double half_b = dot(oc, d);
+    double c = length_squared(oc) - radius * radius;
+    double discriminant = half_b * half_b - a * c;
+    if (discriminant < 0.0) return 0;
+    double sqrtd = sqrt(discriminant);
+    double root = (-half_b - sqrtd) / a;
+    if (root < t_min || t_max < root) {
+        root = (-half_b + sqrtd) / a;
+        if (root < t_min || t_max < root) return 0;
+    }
+    V3 point = ray_at(o, d, root);
+    V3 outward = divs(sub(point, center), radius);
+    double pt[3];
+    v3out(point, pt);
+    orc_sphere_uv(pt, &h->u, &h->v);
+    v3out(point, h->point);
+    h->t = root;
+    set_face_normal(h, d, outward);
+    return 1;
+}
+
+static int hit_bare(const RtPrimitive *prim, V3 o, V3 d, double time, double t_min, double t_max, OrcHit *h) {
     switch (prim->kind) {
+    case RT_PRIM_MOVING_SPHERE: return hit_moving_sphere(prim, o, d, time, t_min, t_max, h);
     case RT_PRIM_SPHERE: return hit_sphere(prim->p, o, d, t_min, t_max, h);
     case RT_PRIM_XY_RECT: return hit_rect(2, prim->p, o, d, t_min, t_max, h);
     case RT_PRIM_XZ_RECT: return hit_rect(1, prim->p, o, d, t_min, t_max, h);
@@ -228,12 +259,12 @@ static int hit_bare(const RtPrimitive *prim, V3 o, V3 d, double t_min, double t_
 }
 
 /* rotate_y.rs:31-64 around the bare primitive */
-static int hit_rotated(const RtPrimitive *prim, V3 o, V3 d, double t_min, double t_max, OrcHit *h) {
-    if (!(prim->flags & RT_PRIM_HAS_ROTATE_Y)) return hit_bare(prim, o, d, t_min, t_max, h);
+static int hit_rotated(const RtPrimitive *prim, V3 o, V3 d, double time, double t_min, double t_max, OrcHit *h) {
+    if (!(prim->flags & RT_PRIM_HAS_ROTATE_Y)) return hit_bare(prim, o, d, time, t_min, t_max, h);
     double s = prim->rot_sin, c = prim->rot_cos;
     V3 ro = v3(c * o.x - s * o.z, o.y, s * o.x + c * o.z);
     V3 rd = v3(c * d.x - s * d.z, d.y, s * d.x + c * d.z);
-    if (!hit_bare(prim, ro, rd, t_min, t_max, h)) return 0;
+    if (!hit_bare(prim, ro, rd, time, t_min, t_max, h)) return 0;
     V3 pt = v3p(h->point), n = v3p(h->normal);
     V3 wp = v3(c * pt.x + s * pt.z, pt.y, -s * pt.x + c * pt.z);
     V3 wn = v3(c * n.x + s * n.z, n.y, -s * n.x + c * n.z);
@@ -246,19 +277,24 @@ static int hit_rotated(const RtPrimitive *prim, V3 o, V3 d, double t_min, double
 /* translate.rs:24-41 around (rotated) primitive */
 int orc_hit_primitive(const RtPrimitive *prim, const double origin[3], const double dir[3],
                       double t_min, double t_max, OrcHit *out) {
+    return orc_hit_primitive_time(prim, origin, dir, 0.0, t_min, t_max, out);
+}
+
+int orc_hit_primitive_time(const RtPrimitive *prim, const double origin[3], const double dir[3], double time,
+                           double t_min, double t_max, OrcHit *out) {
     V3 o = v3p(origin), d = v3p(dir);
     int hit;
     if (prim->flags & RT_PRIM_HAS_TRANSLATE) {
         V3 off = v3p(prim->translate);
         V3 mo = sub(o, off);
-        hit = hit_rotated(prim, mo, d, t_min, t_max, out);
+        hit = hit_rotated(prim, mo, d, time, t_min, t_max, out);
         if (hit) {
             v3out(add(v3p(out->point), off), out->point);
             /* translate.rs:36: set_face_normal with the already-flipped normal */
             set_face_normal(out, d, v3p(out->normal));
         }
     } else {
-        hit = hit_rotated(prim, o, d, t_min, t_max, out);
+        hit = hit_rotated(prim, o, d, time, t_min, t_max, out);
     }
     if (hit) {
         out->material = prim->material;
@@ -288,6 +324,18 @@ void orc_primitive_aabb(const RtPrimitive *prim, double mn[3], double mx[3]) {
         pos = v3(p[4], p[0], p[2]);
         aabb_new(v3(p[4] - 0.0001, p[0], p[2]), v3(p[4] + 0.0001, p[1], p[3]), mn, mx);
         break;
+    case RT_PRIM_MOVING_SPHERE: { /* moving_sphere.rs:93-106: union of the boxes at pos_a and pos_b */
+        double mn2[3], mx2[3];
+        V3 r3 = v3(p[3], p[3], p[3]), pb = v3p(prim->center_b);
+        pos = v3(p[0], p[1], p[2]);
+        aabb_new(sub(pos, r3), add(pos, r3), mn, mx);
+        aabb_new(sub(pb, r3), add(pb, r3), mn2, mx2);
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = fmin(mn[a], mn2[a]);
+            mx[a] = fmax(mx[a], mx2[a]);
+        }
+        break;
+    }
     default: /* box.rs:103-110, geometry_creation.rs:95-103 */
         pos = v3(p[0], p[1], p[2]);
         aabb_new(v3(p[0], p[1], p[2]), v3(p[3], p[4], p[5]), mn, mx);
@@ -408,31 +456,36 @@ void orc_scene_free(OrcScene *s) {
 }
 
 /* bvh_node.rs:112-132 */
-static int bvh_hit(const OrcScene *s, int ni, const double o[3], const double d[3],
+static int bvh_hit(const OrcScene *s, int ni, const double o[3], const double d[3], double time,
                    double t_min, double t_max, OrcHit *out) {
     const BvhNode *node = &s->nodes[ni];
     if (!orc_aabb_hit(node->mn, node->mx, o, d, t_min, t_max)) return 0;
     if (node->leaf_prim >= 0)
-        return orc_hit_primitive(&s->desc->primitives[node->leaf_prim], o, d, t_min, t_max, out);
+        return orc_hit_primitive_time(&s->desc->primitives[node->leaf_prim], o, d, time, t_min, t_max, out);
     OrcHit l;
-    if (bvh_hit(s, node->left, o, d, t_min, t_max, &l)) {
+    if (bvh_hit(s, node->left, o, d, time, t_min, t_max, &l)) {
         OrcHit r;
-        if (bvh_hit(s, node->right, o, d, t_min, l.t, &r)) *out = r; else *out = l;
+        if (bvh_hit(s, node->right, o, d, time, t_min, l.t, &r)) *out = r; else *out = l;
         return 1;
     }
-    return bvh_hit(s, node->right, o, d, t_min, t_max, out);
+    return bvh_hit(s, node->right, o, d, time, t_min, t_max, out);
 }
 
 int orc_scene_hit(const OrcScene *s, const double origin[3], const double dir[3],
                   double t_min, double t_max, OrcHit *out) {
+    return orc_scene_hit_time(s, origin, dir, 0.0, t_min, t_max, out);
+}
+
+int orc_scene_hit_time(const OrcScene *s, const double origin[3], const double dir[3], double time,
+                       double t_min, double t_max, OrcHit *out) {
     if (s->desc->n_primitives <= 0) return 0; /* SURVEY B-18: reference would hang */
-    if (s->use_bvh) return bvh_hit(s, s->root, origin, dir, t_min, t_max, out);
+    if (s->use_bvh) return bvh_hit(s, s->root, origin, dir, time, t_min, t_max, out);
     /* linear scan with shrinking t_max (shared_scene.rs) */
     int any = 0;
     double closest = t_max;
     for (int i = 0; i < s->desc->n_primitives; ++i) {
         OrcHit tmp;
-        if (orc_hit_primitive(&s->desc->primitives[i], origin, dir, t_min, closest, &tmp)) {
+        if (orc_hit_primitive_time(&s->desc->primitives[i], origin, dir, time, t_min, closest, &tmp)) {
             closest = tmp.t;
             *out = tmp;
             any = 1;
@@ -625,13 +678,13 @@ typedef struct {
     uint64_t segments;
 } TraceCtx;
 
-static V3 ray_color(TraceCtx *ctx, V3 o, V3 d, int depth, const PathRng *rng) {
+static V3 ray_color(TraceCtx *ctx, V3 o, V3 d, double time, int depth, const PathRng *rng) {
     if (depth == 0) return v3(1.0, 1.0, 1.0); /* renderer.rs:48-55 */
     double oo[3], dd[3];
     v3out(o, oo); v3out(d, dd);
     OrcHit rec;
     ctx->segments++;
-    if (!orc_scene_hit(ctx->scene, oo, dd, 0.001, INFINITY, &rec)) {
+    if (!orc_scene_hit_time(ctx->scene, oo, dd, time, 0.001, INFINITY, &rec)) {
         double bg[3];
         orc_background_color(&ctx->desc->background, dd, bg);
         return v3p(bg);
@@ -641,7 +694,8 @@ static V3 ray_color(TraceCtx *ctx, V3 o, V3 d, int depth, const PathRng *rng) {
     V3 sdir, att;
     if (!scatter(ctx->desc, m, d, &rec, rng, (uint32_t)(ctx->max_depth - depth), &sdir, &att))
         return emitted;
-    V3 deeper = ray_color(ctx, v3p(rec.point), sdir, depth - 1, rng);
+    /* every Material::scatter builds its ray with ray.time() (e.g. lambertian.rs:35) */
+    V3 deeper = ray_color(ctx, v3p(rec.point), sdir, time, depth - 1, rng);
     return add(emitted, mulv(att, deeper));
 }
 
@@ -676,9 +730,8 @@ void orc_sample_radiance_u(const RtSceneDesc *desc, const OrcScene *scene, const
     V3 o, d;
     double time;
     get_ray(camera, u, v, &rng, &o, &d, &time);
-    (void)time; /* no time-dependent geometry in scope (MovingSphere is f4) */
     TraceCtx ctx = { desc, scene, params->max_depth, 0 };
-    V3 c = ray_color(&ctx, o, d, params->max_depth, &rng);
+    V3 c = ray_color(&ctx, o, d, time, params->max_depth, &rng);
     v3out(c, out);
     if (n_segments) *n_segments = (int)ctx.segments;
 }

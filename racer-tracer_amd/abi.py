@@ -5,7 +5,7 @@ C header; tests/test_abi_layout.py checks the sizes against the C compiler.
 """
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # RtError (reference codes: racer-tracer/src/error.rs:71-97)
 RT_OK = 0
@@ -25,6 +25,7 @@ RT_ERR_OUT_OF_MEMORY = 104
 RT_TEX_SOLID_COLOR, RT_TEX_CHECKERED, RT_TEX_IMAGE, RT_TEX_NOISE = 0, 1, 2, 3
 RT_MAT_LAMBERTIAN, RT_MAT_METAL, RT_MAT_DIELECTRIC, RT_MAT_DIFFUSE_LIGHT = 0, 1, 2, 3
 RT_PRIM_SPHERE, RT_PRIM_XY_RECT, RT_PRIM_XZ_RECT, RT_PRIM_YZ_RECT, RT_PRIM_BOX = 0, 1, 2, 3, 4
+RT_PRIM_MOVING_SPHERE = 5
 RT_PRIM_HAS_ROTATE_Y, RT_PRIM_HAS_TRANSLATE = 1, 2
 RT_BG_SKY, RT_BG_SOLID = 0, 1
 
@@ -54,7 +55,8 @@ class RtMaterial(C.Structure):
 class RtPrimitive(C.Structure):
     _fields_ = [("kind", C.c_int32), ("material", C.c_int32), ("flags", C.c_int32),
                 ("obj_id", C.c_int32), ("p", C.c_double * 6), ("rot_sin", C.c_double),
-                ("rot_cos", C.c_double), ("translate", D3)]
+                ("rot_cos", C.c_double), ("translate", D3), ("center_b", D3), ("time_a", C.c_double),
+                ("time_b", C.c_double)]
 
 
 class RtBackground(C.Structure):
@@ -143,6 +145,12 @@ def sphere(center, radius, material, obj_id=0):
     return RtPrimitive(RT_PRIM_SPHERE, material, 0, obj_id,
                        (C.c_double * 6)(center[0], center[1], center[2], radius, 0.0, 0.0),
                        0.0, 1.0, D3(0, 0, 0))
+
+
+def moving_sphere(center_a, center_b, radius, material, obj_id=0, time_a=0.0, time_b=1.0):
+    return RtPrimitive(RT_PRIM_MOVING_SPHERE, material, 0, obj_id,
+                       (C.c_double * 6)(center_a[0], center_a[1], center_a[2], radius, 0.0, 0.0),
+                       0.0, 1.0, D3(0, 0, 0), D3(*center_b), time_a, time_b)
 
 
 def rect(kind, a0, a1, b0, b1, k, material, obj_id=0):

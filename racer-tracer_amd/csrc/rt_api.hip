@@ -10,6 +10,7 @@
 #include <new>
 #include <string>
 #include <vector>
+#include "rt_bvh.h"
 #include "rt_device_types.h"
 #include "../../include/rt_abi.h"
 
@@ -18,9 +19,9 @@ extern "C" hipError_t rtdev_launch_trace(const rtdev::TraceArgs *args, int prims
 extern "C" hipError_t rtdev_launch_resolve(const double *accum, double *out, int width, int height,
                                            int strip_rows, int strip_count, int strip_index, int samples,
                                            hipStream_t stream);
-extern "C" int rtdev_pool_blocks_per_cu(int prims_class, int textured, int specular);
+extern "C" int rtdev_pool_blocks_per_cu(int prims_class, int textured, int specular, int bvh);
 extern "C" hipError_t rtdev_launch_trace_pool(const rtdev::TraceArgs *args, int prims_class, int textured, int specular,
-                                              unsigned blocks, hipStream_t stream);
+                                              int bvh, unsigned blocks, hipStream_t stream);
 extern "C" hipError_t rtdev_launch_resolve_chunks(const double *partial, double *out, int width, int height, int n_chunks,
                                                   int strip_rows, int strip_count, int strip_index, int samples,
                                                   hipStream_t stream);
@@ -74,6 +75,12 @@ struct RtScene {
     int prims_class = 2;
     int textured = 0; // some material's texture is not a plain SolidColor
     int specular = 0; // some material is Metal or Dielectric
+
+    // closest hit: linear loop for small scenes, skip-link BVH (rt_bvh.h) above kBvhThreshold primitives
+    int use_bvh = 0;
+    DevBuf<rtdev::BvhNode> bvh_nodes;
+    DevBuf<int32_t> bvh_prim_index;
+    int n_bvh_nodes = 0;
 
     // pooled kernel (default): persistent grid = CUs x resident blocks of the variant
     bool use_v1 = false;   // env RT_TRACE_KERNEL=v1: the lane-per-pixel kernel
@@ -136,7 +143,9 @@ int validate_desc(const RtSceneDesc *d) {
     }
     for (int i = 0; i < d->n_primitives; ++i) {
         const RtPrimitive &p = d->primitives[i];
-        if (p.kind < RT_PRIM_SPHERE || p.kind > RT_PRIM_BOX) return fail(RT_ERR_INVALID_ARGUMENT, "unknown primitive kind");
+        if (p.kind < RT_PRIM_SPHERE || p.kind > RT_PRIM_MOVING_SPHERE) return fail(RT_ERR_INVALID_ARGUMENT, "unknown primitive kind");
+        if (p.kind == RT_PRIM_MOVING_SPHERE && (p.flags & (RT_PRIM_HAS_ROTATE_Y | RT_PRIM_HAS_TRANSLATE)))
+            return fail(RT_ERR_UNSUPPORTED, "a MovingSphere cannot be wrapped in RotateY/Translate");
         if (p.material < 0 || p.material >= d->n_materials)
             return fail(RT_ERR_UNKNOWN_MATERIAL, "primitive " + std::to_string(i) + " names a missing material");
     }
@@ -216,9 +225,14 @@ void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtd
         a.cam.vertical[k] = c->vertical[k];
     }
     a.cam.lens_radius = c->lens_radius;
+    a.cam.time_a = c->time_a;
+    a.cam.time_b = c->time_b;
     a.bg = s->bg;
     a.accum = s->accum.ptr;
     a.segments = s->segments.ptr;
+    a.bvh_nodes = s->bvh_nodes.ptr;
+    a.bvh_prim_index = s->bvh_prim_index.ptr;
+    a.n_bvh_nodes = s->n_bvh_nodes;
 }
 
 // Enqueue trace (in sample batches, polling `cancel` between them) + resolve.
@@ -287,7 +301,7 @@ int enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, 
             unsigned blocks = (unsigned)(s->num_cus * s->pool_blocks_per_cu);
             unsigned needed = (a.n_items + 3) / 4;
             if (blocks > needed) blocks = needed;
-            RT_HIP(rtdev_launch_trace_pool(&a, s->prims_class, s->textured, s->specular, blocks, stream));
+            RT_HIP(rtdev_launch_trace_pool(&a, s->prims_class, s->textured, s->specular, s->use_bvh, blocks, stream));
             chunks_done += a.n_chunks;
             ++launches;
             if (cancel) RT_HIP(hipStreamSynchronize(stream)); // so the next poll is meaningful
@@ -368,6 +382,8 @@ void rt_scene_destroy(RtScene *s) {
     s->textures.release();
     s->images.release();
     s->perlins.release();
+    s->bvh_nodes.release();
+    s->bvh_prim_index.release();
     s->accum.release();
     s->partial.release();
     s->queue.release();
@@ -410,7 +426,12 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
         q.kind = p.kind;
         q.flags = p.flags & (RT_PRIM_HAS_ROTATE_Y | RT_PRIM_HAS_TRANSLATE);
         q.material = p.material;
-        q.inv_radius = p.kind == RT_PRIM_SPHERE ? 1.0 / p.p[3] : 0.0;
+        q.inv_radius = (p.kind == RT_PRIM_SPHERE || p.kind == RT_PRIM_MOVING_SPHERE) ? 1.0 / p.p[3] : 0.0;
+        if (p.kind == RT_PRIM_MOVING_SPHERE) { // device packing: tr = pos_b - pos_a, rot_sin = time_a, rot_cos = 1/(time_b - time_a)
+            for (int k = 0; k < 3; ++k) q.tr[k] = p.center_b[k] - p.p[k];
+            q.rot_sin = p.time_a;
+            q.rot_cos = 1.0 / (p.time_b - p.time_a);
+        }
     }
     std::vector<rtdev::Texture> textures((size_t)d->n_textures);
     for (int i = 0; i < d->n_textures; ++i) {
@@ -469,6 +490,18 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
         if (q.kind == RT_MAT_METAL || q.kind == RT_MAT_DIELECTRIC) s->specular = 1;
         if (q.kind != RT_MAT_DIELECTRIC && q.tex_kind != RT_TEX_SOLID_COLOR) s->textured = 1;
     }
+    // The linear loop costs ~35 VALU instructions per primitive with scalar loads and
+    // no divergence; the BVH walk ~25 node visits plus leaf tests with per-lane loads.
+    // They cross at a few dozen primitives (clown.yml, 23 spheres, is still linear).
+    const int kBvhThreshold = 48;
+    s->use_bvh = d->n_primitives > kBvhThreshold;
+    if (const char *k = getenv("RT_BVH")) s->use_bvh = atoi(k) != 0 && d->n_primitives > 0; // developer knob
+    if (s->use_bvh) {
+        rtdev::BvhBuild bvh = rtdev::build_bvh(d->primitives, d->n_primitives);
+        if ((rc = upload(s->bvh_nodes, bvh.nodes)) != RT_OK) return rc;
+        if ((rc = upload(s->bvh_prim_index, bvh.prim_index)) != RT_OK) return rc;
+        s->n_bvh_nodes = (int)bvh.nodes.size();
+    }
     if ((rc = upload(s->prims, prims)) != RT_OK) return rc;
     if ((rc = upload(s->textures, textures)) != RT_OK) return rc;
     if ((rc = upload(s->materials, materials)) != RT_OK) return rc;
@@ -486,7 +519,7 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     }
     if (const char *k = getenv("RT_TRACE_KERNEL")) s->use_v1 = strcmp(k, "v1") == 0;
     RT_HIP(hipDeviceGetAttribute(&s->num_cus, hipDeviceAttributeMultiprocessorCount, device));
-    s->pool_blocks_per_cu = rtdev_pool_blocks_per_cu(s->prims_class, s->textured, s->specular);
+    s->pool_blocks_per_cu = rtdev_pool_blocks_per_cu(s->prims_class, s->textured, s->specular, s->use_bvh);
     if (const char *k = getenv("RT_POOL_BLOCKS_PER_CU")) // developer knob for occupancy experiments
         if (atoi(k) > 0) s->pool_blocks_per_cu = atoi(k);
     RT_HIP(s->segments.alloc(1));

@@ -1,0 +1,136 @@
+// rt_bvh.cpp — see rt_bvh.h.
+#include "rt_bvh.h"
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+
+namespace rtdev {
+
+void primitive_bounds(const RtPrimitive &p, double mn[3], double mx[3]) {
+    double lo[3], hi[3];
+    switch (p.kind) {
+    case RT_PRIM_SPHERE:
+    case RT_PRIM_MOVING_SPHERE: {
+        double r = std::fabs(p.p[3]);
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = p.p[k] - r;
+            hi[k] = p.p[k] + r;
+            if (p.kind == RT_PRIM_MOVING_SPHERE) { // swept between the two centres
+                lo[k] = std::min(lo[k], p.center_b[k] - r);
+                hi[k] = std::max(hi[k], p.center_b[k] + r);
+            }
+        }
+        break;
+    }
+    case RT_PRIM_XY_RECT: lo[0] = p.p[0]; hi[0] = p.p[1]; lo[1] = p.p[2]; hi[1] = p.p[3]; lo[2] = hi[2] = p.p[4]; break;
+    case RT_PRIM_XZ_RECT: lo[0] = p.p[0]; hi[0] = p.p[1]; lo[2] = p.p[2]; hi[2] = p.p[3]; lo[1] = hi[1] = p.p[4]; break;
+    case RT_PRIM_YZ_RECT: lo[1] = p.p[0]; hi[1] = p.p[1]; lo[2] = p.p[2]; hi[2] = p.p[3]; lo[0] = hi[0] = p.p[4]; break;
+    default:
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::min(p.p[k], p.p[3 + k]);
+            hi[k] = std::max(p.p[k], p.p[3 + k]);
+        }
+        break;
+    }
+    for (int k = 0; k < 3; ++k)
+        if (lo[k] > hi[k]) std::swap(lo[k], hi[k]);
+    if (p.flags & RT_PRIM_HAS_ROTATE_Y) { // object -> world: x' = c x + s z, z' = -s x + c z (rotate_y.rs:55-59)
+        double s = p.rot_sin, c = p.rot_cos;
+        double nlo[3] = {DBL_MAX, lo[1], DBL_MAX}, nhi[3] = {-DBL_MAX, hi[1], -DBL_MAX};
+        for (int i = 0; i < 2; ++i)
+            for (int k = 0; k < 2; ++k) {
+                double x = i ? hi[0] : lo[0], z = k ? hi[2] : lo[2];
+                double wx = c * x + s * z, wz = -s * x + c * z;
+                nlo[0] = std::min(nlo[0], wx); nhi[0] = std::max(nhi[0], wx);
+                nlo[2] = std::min(nlo[2], wz); nhi[2] = std::max(nhi[2], wz);
+            }
+        for (int k = 0; k < 3; ++k) { lo[k] = nlo[k]; hi[k] = nhi[k]; }
+    }
+    if (p.flags & RT_PRIM_HAS_TRANSLATE)
+        for (int k = 0; k < 3; ++k) { lo[k] += p.translate[k]; hi[k] += p.translate[k]; }
+    for (int k = 0; k < 3; ++k) { // inflate: the slab test must never be stricter than the primitive's own test
+        double pad = 1e-9 * std::max({std::fabs(lo[k]), std::fabs(hi[k]), hi[k] - lo[k], 1e-3});
+        mn[k] = lo[k] - pad;
+        mx[k] = hi[k] + pad;
+    }
+}
+
+namespace {
+
+struct Item {
+    double mn[3], mx[3], centroid[3];
+    int32_t prim;
+};
+
+// Emits the subtree over items[begin, end) in depth-first order; returns its root index.
+int emit(BvhBuild &out, std::vector<Item> &items, int begin, int end) {
+    int me = (int)out.nodes.size();
+    out.nodes.emplace_back();
+    double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    double cmn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, cmx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    for (int i = begin; i < end; ++i)
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = std::min(mn[k], items[(size_t)i].mn[k]);
+            mx[k] = std::max(mx[k], items[(size_t)i].mx[k]);
+            cmn[k] = std::min(cmn[k], items[(size_t)i].centroid[k]);
+            cmx[k] = std::max(cmx[k], items[(size_t)i].centroid[k]);
+        }
+    int n = end - begin;
+    bool leaf = n <= 4;
+    int axis = 0;
+    if (!leaf) {
+        for (int k = 1; k < 3; ++k)
+            if (cmx[k] - cmn[k] > cmx[axis] - cmn[axis]) axis = k;
+        if (!(cmx[axis] - cmn[axis] > 0.0)) leaf = n <= 64; // coincident centroids: splitting cannot separate them
+    }
+    if (leaf && n > 4) { // degenerate pile: chain of 4-primitive leaves under one box
+        leaf = false;
+        axis = -1;
+    }
+    BvhNode node;
+    for (int k = 0; k < 3; ++k) { node.mn[k] = mn[k]; node.mx[k] = mx[k]; }
+    node._pad = 0;
+    if (leaf) {
+        node.first = (int32_t)out.prim_index.size();
+        node.count = n;
+        for (int i = begin; i < end; ++i) out.prim_index.push_back(items[(size_t)i].prim);
+        node.skip = me + 1;
+        out.nodes[(size_t)me] = node;
+        return me;
+    }
+    int mid = begin + n / 2;
+    if (axis >= 0)
+        std::nth_element(items.begin() + begin, items.begin() + mid, items.begin() + end,
+                         [axis](const Item &a, const Item &b) {
+                             if (a.centroid[axis] != b.centroid[axis]) return a.centroid[axis] < b.centroid[axis];
+                             return a.prim < b.prim; // deterministic on ties
+                         });
+    else
+        mid = begin + 4;
+    node.first = -1;
+    node.count = 0;
+    out.nodes[(size_t)me] = node;
+    emit(out, items, begin, mid);
+    emit(out, items, mid, end);
+    out.nodes[(size_t)me].skip = (int32_t)out.nodes.size();
+    return me;
+}
+
+} // namespace
+
+BvhBuild build_bvh(const RtPrimitive *prims, int n_prims) {
+    BvhBuild out;
+    if (n_prims <= 0) return out;
+    std::vector<Item> items((size_t)n_prims);
+    for (int i = 0; i < n_prims; ++i) {
+        Item &it = items[(size_t)i];
+        primitive_bounds(prims[i], it.mn, it.mx);
+        for (int k = 0; k < 3; ++k) it.centroid[k] = 0.5 * (it.mn[k] + it.mx[k]);
+        it.prim = i;
+    }
+    out.nodes.reserve((size_t)n_prims);
+    emit(out, items, 0, n_prims);
+    return out;
+}
+
+} // namespace rtdev

@@ -1,0 +1,35 @@
+// rt_bvh.h — bounding-volume hierarchy for scenes too large for the
+// brute-force closest-hit loop.
+//
+// The reference walks a binary BVH with one object per leaf, random split
+// axis in {x, y} and both children always visited (bvh_node.rs:31-132).  Only
+// its RESULT is part of the contract — the closest hit in [t_min, t_max],
+// topology-free except for exact ties (SURVEY B-15) — so this one is built for
+// the GPU instead: median split on the longest centroid axis, up to four
+// primitives per leaf, nodes stored in depth-first order with a skip link, so
+// a lane walks it with one integer of state and no stack:
+//
+//     i = 0;  while (i < n) { if (ray hits node i) { test its primitives (leaf); i = i + 1 or skip } else i = skip[i]; }
+//
+// Boxes are the TRUE bounds of the primitives (not rotate_y.rs:66-90's
+// mis-sized ones), inflated by 1e-9 relative so the slab test can never
+// reject a primitive whose own intersection routine accepts the ray.
+#pragma once
+#include <stdint.h>
+#include <vector>
+#include "../../include/rt_abi.h"
+#include "rt_device_types.h"
+
+namespace rtdev {
+
+struct BvhBuild {
+    std::vector<BvhNode> nodes;
+    std::vector<int32_t> prim_index; // leaves refer to ranges of this list
+};
+
+// Host-side build over the ABI primitives (wrappers and motion included in the bounds).
+BvhBuild build_bvh(const RtPrimitive *prims, int n_prims);
+// True bounds of one primitive incl. RotateY / Translate / motion.
+void primitive_bounds(const RtPrimitive &p, double mn[3], double mx[3]);
+
+} // namespace rtdev

@@ -56,9 +56,19 @@ struct Perlin { // gradient table only: perm tables are folded into `index`
     int32_t perm_x[256], perm_y[256], perm_z[256];
 };
 
+struct alignas(16) BvhNode { // 64 B; depth-first order with a skip link (rt_bvh.h)
+    double mn[3], mx[3];
+    int32_t skip;   // next node when this subtree is finished or missed (n_nodes = done)
+    int32_t first;  // leaf: first entry in the primitive index list; inner: -1
+    int32_t count;  // leaf: number of primitives (1..4); inner: 0
+    int32_t _pad;
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+
 struct Camera { // what get_ray reads (camera.rs:326-337)
     double origin[3], ulc[3], right[3], up[3], horizontal[3], vertical[3];
     double lens_radius;
+    double time_a, time_b; // ray time = R(time_a, time_b), camera.rs:335 (read by MovingSphere only)
 };
 
 struct Background {
@@ -98,6 +108,10 @@ struct TraceArgs {
     int32_t tiles_x, n_tiles;    // 8x8 tiles over width x owned_rows
     // cpu.rs:36,40 divide by (W-1) and (H-1); the pooled kernel multiplies by these
     double inv_width_m1, inv_height_m1;
+    // BVH (scenes with more primitives than the brute-force loop is good for)
+    const BvhNode *bvh_nodes;
+    const int32_t *bvh_prim_index;
+    int32_t n_bvh_nodes, _pad_bvh;
 };
 
 } // namespace rtdev

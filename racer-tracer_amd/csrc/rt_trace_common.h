@@ -183,8 +183,9 @@ __device__ __forceinline__ void box_side(const double *p, int s, int &axis, doub
 // (translate.rs:31, rotate_y.rs:39-48).  aux = box side.
 template <int PRIMS>
 // inv_d = 1/d (component-wise) and inv_a = 1/|d|^2 are computed once per ray.
-__device__ __forceinline__ bool prim_t(const Prim &P, d3 o, d3 d, d3 inv_d, double inv_a, double t_min, double t_max,
-                                       double &t_out, int &aux) {
+// `time` is the ray's time (ray.rs:26-28); only MovingSphere reads it.
+__device__ __forceinline__ bool prim_t(const Prim &P, d3 o, d3 d, d3 inv_d, double inv_a, double time, double t_min,
+                                       double t_max, double &t_out, int &aux) {
     aux = 0;
     if (PRIMS == PRIMS_RECTS) { // untransformed rects only: kind picks the axis
         int kind = P.kind;
@@ -201,8 +202,12 @@ __device__ __forceinline__ bool prim_t(const Prim &P, d3 o, d3 d, d3 inv_d, doub
         }
     }
     switch (PRIMS == PRIMS_SPHERES ? (int)RT_PRIM_SPHERE : P.kind) {
+    case RT_PRIM_MOVING_SPHERE: // moving_sphere.rs:37-39,49-69: same quadratic around the centre at `time`
     case RT_PRIM_SPHERE: { // sphere.rs:39-59
-        d3 oc = o - ld3(P.p);
+        d3 center = ld3(P.p);
+        if (PRIMS == PRIMS_ANY && P.kind == RT_PRIM_MOVING_SPHERE)
+            center = center + ((time - P.rot_sin) * P.rot_cos) * ld3(P.tr); // tr = pos_b - pos_a, rot_* = time_a, 1/(time_b - time_a)
+        d3 oc = o - center;
         double a = len2(d);
         double half_b = dot(oc, d);
         double c = len2(oc) - P.p[3] * P.p[3];
@@ -240,6 +245,42 @@ __device__ __forceinline__ bool prim_t(const Prim &P, d3 o, d3 d, d3 inv_d, doub
     }
 }
 
+// Closest hit through the skip-link BVH (rt_bvh.h): one integer of traversal
+// state per lane, no stack.  Same acceptance rule as the brute-force loop
+// (t in [t_min, best_t], later equal hit wins), so only exact ties can differ.
+template <int PRIMS>
+__device__ __forceinline__ void closest_hit_bvh(const TraceArgs &A, d3 o, d3 d, d3 inv_d, double inv_a, double time,
+                                                double t_min, double &best_t, int &best, int &best_aux) {
+    int i = 0;
+    const int n = A.n_bvh_nodes;
+    while (i < n) {
+        const BvhNode *N = &A.bvh_nodes[i];
+        const double ax = (N->mn[0] - o.x) * inv_d.x, bx = (N->mx[0] - o.x) * inv_d.x;
+        const double ay = (N->mn[1] - o.y) * inv_d.y, by = (N->mx[1] - o.y) * inv_d.y;
+        const double az = (N->mn[2] - o.z) * inv_d.z, bz = (N->mx[2] - o.z) * inv_d.z;
+        // fmin/fmax drop NaNs (0 * inf on a slab boundary), which keeps the test conservative
+        const double t_near = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmax(fmin(az, bz), t_min));
+        const double t_far = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmin(fmax(az, bz), best_t));
+        if (t_near <= t_far) {
+            const int count = N->count;
+            const int first = N->first;
+            for (int k = 0; k < count; ++k) {
+                const int pi = A.bvh_prim_index[first + k];
+                double t;
+                int aux;
+                if (prim_t<PRIMS>(A.prims[pi], o, d, inv_d, inv_a, time, t_min, best_t, t, aux)) {
+                    best_t = t;
+                    best = pi;
+                    best_aux = aux;
+                }
+            }
+            i = i + 1; // inner: first child; leaf: its skip link is i + 1 as well
+        } else {
+            i = N->skip;
+        }
+    }
+}
+
 // sphere.rs:20-27; out of line: acos/atan2 are large and only image textures read u,v
 __device__ __noinline__ void sphere_uv(d3 outward, double &u, double &v) {
     const double PI = 3.14159265358979323846;
@@ -251,7 +292,7 @@ __device__ __noinline__ void sphere_uv(d3 outward, double &u, double &v) {
 
 // Rebuild the HitRecord of the winning primitive (geometry.rs:17-57).
 template <int PRIMS, bool TEXTURED>
-__device__ __forceinline__ Hit prim_hit_record(const Prim &P, d3 o, d3 d, double t, int aux, bool want_uv) {
+__device__ __forceinline__ Hit prim_hit_record(const Prim &P, d3 o, d3 d, double time, double t, int aux, bool want_uv) {
     d3 oo = o, dd = d;
     const int flags = PRIMS == PRIMS_ANY ? P.flags : 0;
     if (flags & RT_PRIM_HAS_TRANSLATE) oo = oo - ld3(P.tr);
@@ -264,7 +305,12 @@ __device__ __forceinline__ Hit prim_hit_record(const Prim &P, d3 o, d3 d, double
     h.u = 0.0;
     h.v = 0.0;
     const int kind = PRIMS == PRIMS_SPHERES ? (int)RT_PRIM_SPHERE : P.kind;
-    if (PRIMS != PRIMS_RECTS && kind == RT_PRIM_SPHERE) {
+    if (PRIMS == PRIMS_ANY && kind == RT_PRIM_MOVING_SPHERE) {
+        const d3 center = ld3(P.p) + ((time - P.rot_sin) * P.rot_cos) * ld3(P.tr);
+        d3 outward = (h.point - center) * P.inv_radius; // moving_sphere.rs:75
+        if (TEXTURED && want_uv) sphere_uv(h.point, h.u, h.v); // moving_sphere.rs:76: uv of the POINT (SURVEY B-19)
+        set_face_normal(h, dd, outward);
+    } else if (PRIMS != PRIMS_RECTS && kind == RT_PRIM_SPHERE) {
         d3 outward = (h.point - ld3(P.p)) * P.inv_radius; // sphere.rs:61
         if (TEXTURED && want_uv) sphere_uv(outward, h.u, h.v);
         set_face_normal(h, dd, outward);

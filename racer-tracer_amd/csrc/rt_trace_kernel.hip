@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void k_trace_f64(const TraceArgs A) {
     d3 o = sum, d = sum, T = sum;
     int s = in_image ? A.sample_begin : A.sample_end;
     uint32_t seg = 0;
+    double ray_time = 0.0; // ray.rs:26-28; scattered rays inherit it
     bool alive = false;
     unsigned int n_segments = 0;
 
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void k_trace_f64(const TraceArgs A) {
             d3 co = ld3(A.cam.origin);
             o = co + offset;
             d = ld3(A.cam.ulc) + u * ld3(A.cam.horizontal) - v * ld3(A.cam.vertical) - co - offset;
-            // ray time (camera.rs:335) is drawn by the oracle but no primitive in scope reads it
+            ray_time = A.cam.time_a + (A.cam.time_b - A.cam.time_a) * u53(bc.c, bc.d); // camera.rs:335
             T = mk(1.0, 1.0, 1.0);
             seg = 0;
             alive = true;
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void k_trace_f64(const TraceArgs A) {
             for (int i = 0; i < A.n_prims; ++i) {
                 double t;
                 int aux;
-                if (prim_t<PRIMS>(load_prim_uniform(A.prims, i), o, d, inv_d, inv_a, 0.001, best_t, t, aux)) {
+                if (prim_t<PRIMS>(load_prim_uniform(A.prims, i), o, d, inv_d, inv_a, ray_time, 0.001, best_t, t, aux)) {
                     best_t = t;
                     best = i;
                     best_aux = aux;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void k_trace_f64(const TraceArgs A) {
             } else {
                 const Prim &P = A.prims[best];
                 const Material &M = A.materials[P.material];
-                Hit h = prim_hit_record<PRIMS, TEXTURED>(P, o, d, best_t, best_aux, M.needs_uv != 0);
+                Hit h = prim_hit_record<PRIMS, TEXTURED>(P, o, d, ray_time, best_t, best_aux, M.needs_uv != 0);
                 if (M.kind == RT_MAT_DIFFUSE_LIGHT) { // diffuse_light.rs:25-37
                     contrib = T * texture_value<TEXTURED>(A, nullptr, M, h.u, h.v, h.point);
                     ended = true;

@@ -129,8 +129,10 @@ __device__ __forceinline__ void coop_random_in_unit_disk(bool need, uint32_t pix
     }
 }
 
-template <int PRIMS, bool TEXTURED, bool SPECULAR>
-__global__ __launch_bounds__(256, TEXTURED ? 3 : 5) void k_trace_pool_f64(const TraceArgs A) {
+// BVH: closest hit through the skip-link hierarchy instead of the linear loop
+// (instantiated for PRIMS_ANY only; chosen for scenes with many primitives).
+template <int PRIMS, bool TEXTURED, bool SPECULAR, bool BVH>
+__global__ __launch_bounds__(256, TEXTURED ? 3 : (BVH ? 4 : 5)) void k_trace_pool_f64(const TraceArgs A) {
     __shared__ WaveLds lds_all[4];
     // The first Perlin table (9 KB: 256 gradients + permutations) is staged in LDS
     // once per block; the 56 random gradient fetches of a marble lookup then hit
@@ -191,6 +193,7 @@ __global__ __launch_bounds__(256, TEXTURED ? 3 : 5) void k_trace_pool_f64(const 
         PathRng rng{0, 0, A.seed_lo, A.seed_hi};
         d3 o = mk(0, 0, 0), d = o, T = o;
         uint32_t seg = 0;
+        double ray_time = 0.0; // ray.rs:26-28; scattered rays inherit it (e.g. lambertian.rs:35)
         // A lane whose hit needs a random_in_unit_sphere sample that the wave has not
         // found yet stays `waiting` (it keeps its hit below and skips tracing) until a
         // later iteration's sampler rounds reach its accepted candidate.
@@ -240,7 +243,8 @@ __global__ __launch_bounds__(256, TEXTURED ? 3 : 5) void k_trace_pool_f64(const 
                 const d3 co = ld3(A.cam.origin);
                 o = co + offset;
                 d = ld3(A.cam.ulc) + u * ld3(A.cam.horizontal) - v * ld3(A.cam.vertical) - co - offset;
-                // (ray time, camera.rs:335, is drawn by the oracle; nothing in scope reads it)
+                // camera.rs:335: the ray's time, second double of the same block (MovingSphere reads it)
+                if (PRIMS == PRIMS_ANY) ray_time = A.cam.time_a + (A.cam.time_b - A.cam.time_a) * u53(bc.c, bc.d);
                 T = mk(1.0, 1.0, 1.0);
                 seg = 0;
                 alive = true;
@@ -262,13 +266,17 @@ __global__ __launch_bounds__(256, TEXTURED ? 3 : 5) void k_trace_pool_f64(const 
                     int best = -1, best_aux = 0;
                     const d3 inv_d = rcp3(d);
                     const double inv_a = PRIMS == PRIMS_RECTS ? 0.0 : rcp_f64(len2(d));
-                    for (int i = 0; i < A.n_prims; ++i) {
-                        double t;
-                        int aux;
-                        if (prim_t<PRIMS>(load_prim_uniform(A.prims, i), o, d, inv_d, inv_a, 0.001, best_t, t, aux)) {
-                            best_t = t;
-                            best = i;
-                            best_aux = aux;
+                    if (BVH) {
+                        closest_hit_bvh<PRIMS>(A, o, d, inv_d, inv_a, ray_time, 0.001, best_t, best, best_aux);
+                    } else {
+                        for (int i = 0; i < A.n_prims; ++i) {
+                            double t;
+                            int aux;
+                            if (prim_t<PRIMS>(load_prim_uniform(A.prims, i), o, d, inv_d, inv_a, ray_time, 0.001, best_t, t, aux)) {
+                                best_t = t;
+                                best = i;
+                                best_aux = aux;
+                            }
                         }
                     }
                     if (best < 0) { // background_color.rs:27-33 / :45-48
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(256, TEXTURED ? 3 : 5) void k_trace_pool_f64(const 
                     } else {
                         const Prim &P = A.prims[best];
                         const Material &M = A.materials[P.material];
-                        const Hit h = prim_hit_record<PRIMS, TEXTURED>(P, o, d, best_t, best_aux, M.needs_uv != 0);
+                        const Hit h = prim_hit_record<PRIMS, TEXTURED>(P, o, d, ray_time, best_t, best_aux, M.needs_uv != 0);
                         const int kind = M.kind;
                         if (kind == RT_MAT_DIFFUSE_LIGHT) { // diffuse_light.rs:25-37
                             contrib = T * texture_value<TEXTURED>(A, lds_perlin, M, h.u, h.v, h.point);
@@ -414,49 +422,46 @@ __global__ __launch_bounds__(256) void k_resolve_chunks_f64(const double *__rest
 } // namespace rtdev
 
 namespace {
-template <int PRIMS, bool TEXTURED, bool SPECULAR>
-void launch_pool_variant(const rtdev::TraceArgs &a, unsigned blocks, hipStream_t stream) {
-    hipLaunchKernelGGL((rtdev::k_trace_pool_f64<PRIMS, TEXTURED, SPECULAR>), dim3(blocks), dim3(256), 0, stream, a);
-}
-template <int PRIMS>
-void launch_pool_prims(const rtdev::TraceArgs &a, bool textured, bool specular, unsigned blocks, hipStream_t stream) {
-    if (textured) {
-        if (specular) launch_pool_variant<PRIMS, true, true>(a, blocks, stream);
-        else launch_pool_variant<PRIMS, true, false>(a, blocks, stream);
-    } else {
-        if (specular) launch_pool_variant<PRIMS, false, true>(a, blocks, stream);
-        else launch_pool_variant<PRIMS, false, false>(a, blocks, stream);
+// One table entry per compiled variant: PRIMS x TEXTURED x SPECULAR with the
+// linear closest-hit loop, plus PRIMS_ANY x TEXTURED x SPECULAR with the BVH.
+template <int PRIMS, bool TEXTURED, bool SPECULAR, bool BVH> struct PoolVariant {
+    static void launch(const rtdev::TraceArgs &a, unsigned blocks, hipStream_t stream) {
+        hipLaunchKernelGGL((rtdev::k_trace_pool_f64<PRIMS, TEXTURED, SPECULAR, BVH>), dim3(blocks), dim3(256), 0, stream, a);
     }
-}
-template <int PRIMS, bool TEXTURED, bool SPECULAR> int pool_blocks_per_cu() {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rtdev::k_trace_pool_f64<PRIMS, TEXTURED, SPECULAR>, 256, 0) != hipSuccess)
-        return 1;
-    return n < 1 ? 1 : n;
-}
-template <int PRIMS> int pool_blocks_prims(bool textured, bool specular) {
-    if (textured) return specular ? pool_blocks_per_cu<PRIMS, true, true>() : pool_blocks_per_cu<PRIMS, true, false>();
-    return specular ? pool_blocks_per_cu<PRIMS, false, true>() : pool_blocks_per_cu<PRIMS, false, false>();
+    static int blocks_per_cu() {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rtdev::k_trace_pool_f64<PRIMS, TEXTURED, SPECULAR, BVH>, 256, 0) != hipSuccess)
+            return 1;
+        return n < 1 ? 1 : n;
+    }
+};
+
+// Calls F::template run<Variant>() for the variant the flags select.
+template <class F> auto dispatch_variant(int prims_class, bool textured, bool specular, bool bvh, F f) {
+    using namespace rtdev;
+#define RT_PICK(P, B)                                                                           \
+    (textured ? (specular ? f(PoolVariant<P, true, true, B>()) : f(PoolVariant<P, true, false, B>())) \
+              : (specular ? f(PoolVariant<P, false, true, B>()) : f(PoolVariant<P, false, false, B>())))
+    if (bvh) return RT_PICK(PRIMS_ANY, true);
+    if (prims_class == PRIMS_RECTS) return RT_PICK(PRIMS_RECTS, false);
+    if (prims_class == PRIMS_SPHERES) return RT_PICK(PRIMS_SPHERES, false);
+    return RT_PICK(PRIMS_ANY, false);
+#undef RT_PICK
 }
 } // namespace
 
 // Resident blocks per CU of the variant (the persistent grid is CUs x this).
-extern "C" int rtdev_pool_blocks_per_cu(int prims_class, int textured, int specular) {
-    switch (prims_class) {
-    case rtdev::PRIMS_RECTS: return pool_blocks_prims<rtdev::PRIMS_RECTS>(textured != 0, specular != 0);
-    case rtdev::PRIMS_SPHERES: return pool_blocks_prims<rtdev::PRIMS_SPHERES>(textured != 0, specular != 0);
-    default: return pool_blocks_prims<rtdev::PRIMS_ANY>(textured != 0, specular != 0);
-    }
+extern "C" int rtdev_pool_blocks_per_cu(int prims_class, int textured, int specular, int bvh) {
+    return dispatch_variant(prims_class, textured != 0, specular != 0, bvh != 0, [](auto v) { return decltype(v)::blocks_per_cu(); });
 }
 
 extern "C" hipError_t rtdev_launch_trace_pool(const rtdev::TraceArgs *args, int prims_class, int textured, int specular,
-                                              unsigned blocks, hipStream_t stream) {
+                                              int bvh, unsigned blocks, hipStream_t stream) {
     if (blocks == 0 || args->n_items == 0) return hipSuccess;
-    switch (prims_class) {
-    case rtdev::PRIMS_RECTS: launch_pool_prims<rtdev::PRIMS_RECTS>(*args, textured != 0, specular != 0, blocks, stream); break;
-    case rtdev::PRIMS_SPHERES: launch_pool_prims<rtdev::PRIMS_SPHERES>(*args, textured != 0, specular != 0, blocks, stream); break;
-    default: launch_pool_prims<rtdev::PRIMS_ANY>(*args, textured != 0, specular != 0, blocks, stream); break;
-    }
+    dispatch_variant(prims_class, textured != 0, specular != 0, bvh != 0, [&](auto v) {
+        decltype(v)::launch(*args, blocks, stream);
+        return 0;
+    });
     return hipGetLastError();
 }
 

@@ -170,6 +170,14 @@ void Sphere::describe(RtPrimitive &out) const {
     out.p[0] = center.x(); out.p[1] = center.y(); out.p[2] = center.z(); out.p[3] = radius;
 }
 
+void MovingSphere::describe(RtPrimitive &out) const {
+    out.kind = RT_PRIM_MOVING_SPHERE;
+    out.p[0] = pos_a.x(); out.p[1] = pos_a.y(); out.p[2] = pos_a.z(); out.p[3] = radius;
+    for (int k = 0; k < 3; ++k) out.center_b[k] = pos_b[k];
+    out.time_a = time_a;
+    out.time_b = time_b;
+}
+
 void AxisRect::describe(RtPrimitive &out) const {
     out.kind = kind;
     out.p[0] = a0; out.p[1] = a1; out.p[2] = b0; out.p[3] = b1; out.p[4] = k;
@@ -209,6 +217,10 @@ void Translate::describe(RtPrimitive &out) const {
 // geometry_creation.rs
 SceneObject create_sphere(std::shared_ptr<const Material> m, Vec3 pos, double radius) {
     return SceneObject(pos, std::move(m), std::make_shared<Sphere>(pos, radius));
+}
+SceneObject create_movable_sphere(std::shared_ptr<const Material> m, Vec3 pos_a, Vec3 pos_b, double radius,
+                                  double time_a, double time_b) {
+    return SceneObject(pos_a, std::move(m), std::make_shared<MovingSphere>(pos_a, pos_b, radius, time_a, time_b));
 }
 SceneObject create_xy_rect(std::shared_ptr<const Material> m, double x0, double x1, double y0, double y1, double k) {
     return SceneObject(Vec3(x0, y0, k), std::move(m), std::make_shared<AxisRect>(RT_PRIM_XY_RECT, x0, x1, y0, y1, k));
@@ -477,6 +489,63 @@ SceneLoadData SandboxLoader::load() const { // scene/sandbox.rs:39-80
     return data;
 }
 
+SceneLoadData RandomLoader::load() const { // scene/random.rs:25-96
+    // the n-th random_double() of the loader = d0 of block 0 at pixel = n (include/rt_rng.h, RT_RNG_SCENE)
+    uint32_t key[2] = {(uint32_t)(seed_ & 0xffffffffu), (uint32_t)(seed_ >> 32)};
+    uint32_t n = 0;
+    auto random_double = [&]() {
+        uint32_t ctr[4] = {n++, RT_RNG_SAMPLE_TABLE, RT_RNG_SCENE, 0}, out[4];
+        philox4x32_10(ctr, key, out);
+        return u53(out[0], out[1]);
+    };
+    auto random_range = [&](double a, double b) { return a + (b - a) * random_double(); };
+    auto random_color = [&]() { // Vec3::random(): x, y, z in that order (vec3.rs:95-99)
+        double x = random_double(), y = random_double(), z = random_double();
+        return Color(x, y, z);
+    };
+    SceneLoadData data;
+    auto checkered = std::make_shared<Checkered>(std::make_shared<SolidColor>(Color(0.2, 0.3, 0.1)),
+                                                 std::make_shared<SolidColor>(Color(0.9, 0.9, 0.9)));
+    data.objects.push_back(create_sphere(std::make_shared<Lambertian>(checkered), Vec3(0.0, -1000.0, 0.0), 1000.0));
+    for (int a = -11; a < 11; ++a)
+        for (int b = -11; b < 11; ++b) {
+            double choose_mat = random_double();
+            double cx = (double)a + 0.9 * random_double();
+            double cz = (double)b + 0.9 * random_double();
+            Vec3 center(cx, 0.2, cz);
+            if ((center - Vec3(4.0, 0.2, 0.0)).length() > 0.9) {
+                if (choose_mat < 0.8) { // diffuse, moving
+                    Color c1 = random_color();
+                    Color c2 = random_color();
+                    Color albedo = c1 * c2;
+                    Vec3 center2 = center + Vec3(0.0, random_range(0.0, 0.5), 0.0);
+                    data.objects.push_back(create_movable_sphere(Lambertian::new_with_color(albedo), center, center2, 0.2, 0.0, 1.0));
+                } else if (choose_mat > 0.95) { // metal
+                    double r = random_range(0.5, 1.0), g = random_range(0.5, 1.0), bl = random_range(0.5, 1.0);
+                    double fuzz = random_range(0.0, 0.5);
+                    data.objects.push_back(create_sphere(
+                        std::make_shared<Metal>(std::make_shared<SolidColor>(Color(r, g, bl)), fuzz), center, 0.2));
+                } else { // glass
+                    data.objects.push_back(create_sphere(std::make_shared<Dialectric>(1.5), center, 0.2));
+                }
+            }
+        }
+    data.objects.push_back(create_sphere(std::make_shared<Dialectric>(1.5), Vec3(0.0, 1.0, 0.0), 1.0));
+    data.objects.push_back(create_sphere(Lambertian::new_with_color(Color(0.4, 0.2, 0.1)), Vec3(-4.0, 1.0, 0.0), 1.0));
+    data.objects.push_back(create_sphere(
+        std::make_shared<Metal>(std::make_shared<SolidColor>(Color(0.7, 0.6, 0.5)), 0.0), Vec3(4.0, 1.0, 0.0), 1.0));
+    data.background = std::make_unique<Sky>();
+    CameraConfig cam;
+    cam.vfov = 20.0;
+    cam.aperture = 0.1;
+    cam.focus_distance = 10.0;
+    cam.pos = Vec3(0.0, 2.0, 10.0);
+    cam.look_at = Vec3(0.0, 0.0, 0.0);
+    cam.speed = 0.000002;
+    data.camera = cam;
+    return data;
+}
+
 SceneLoadData NoneLoader::load() const { // scene/none.rs
     SceneLoadData data;
     data.background = std::make_unique<Sky>();
@@ -488,9 +557,7 @@ std::unique_ptr<SceneLoader> make_loader(const SceneLoaderConfig &cfg, uint64_t 
     case SceneLoaderConfig::Yml: return std::make_unique<YmlLoader>(cfg.path, seed);
     case SceneLoaderConfig::Sandbox: return std::make_unique<SandboxLoader>("../resources/scenes/cornell_box.yml", seed);
     case SceneLoaderConfig::None: return std::make_unique<NoneLoader>();
-    default:
-        throw TracerError(RT_ERR_UNSUPPORTED,
-                          "the `random` scene (scene/random.rs, MovingSphere) is outside this build's scope");
+    default: return std::make_unique<RandomLoader>(seed);
     }
 }
 

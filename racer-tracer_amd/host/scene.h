@@ -155,6 +155,15 @@ class Sphere : public HittableSceneObject { // geometry/sphere.rs (centre = Scen
     double radius;
 };
 
+class MovingSphere : public HittableSceneObject { // geometry/moving_sphere.rs (pos_a = SceneObject.pos)
+  public:
+    MovingSphere(Vec3 pos_a, Vec3 pos_b, double radius, double time_a, double time_b)
+        : pos_a(pos_a), pos_b(pos_b), radius(radius), time_a(time_a), time_b(time_b) {}
+    void describe(RtPrimitive &out) const override;
+    Vec3 pos_a, pos_b;
+    double radius, time_a, time_b;
+};
+
 class AxisRect : public HittableSceneObject { // geometry/{xy,xz,yz}_rect.rs
   public:
     AxisRect(int kind, double a0, double a1, double b0, double b1, double k) : kind(kind), a0(a0), a1(a1), b0(b0), b1(b1), k(k) {}
@@ -188,6 +197,8 @@ class Translate : public HittableSceneObject { // geometry/translate.rs
 
 // geometry_creation.rs
 SceneObject create_sphere(std::shared_ptr<const Material> m, Vec3 pos, double radius);
+SceneObject create_movable_sphere(std::shared_ptr<const Material> m, Vec3 pos_a, Vec3 pos_b, double radius,
+                                  double time_a, double time_b);
 SceneObject create_xy_rect(std::shared_ptr<const Material> m, double x0, double x1, double y0, double y1, double k);
 SceneObject create_xz_rect(std::shared_ptr<const Material> m, double x0, double x1, double z0, double z1, double k);
 SceneObject create_yz_rect(std::shared_ptr<const Material> m, double y0, double y1, double z0, double z1, double k);
@@ -246,6 +257,19 @@ class SandboxLoader : public SceneLoader { // scene/sandbox.rs:39-80
 
   private:
     std::string path_;
+    uint64_t seed_;
+};
+
+// scene/random.rs: the "book cover" scene, 22 x 22 small spheres (diffuse ones
+// move) + three big ones.  The reference draws it from thread_rng; here the
+// draws come from the contract's RT_RNG_SCENE stream, in the reference's order,
+// so a seed names one scene.
+class RandomLoader : public SceneLoader {
+  public:
+    explicit RandomLoader(uint64_t seed) : seed_(seed) {}
+    SceneLoadData load() const override;
+
+  private:
     uint64_t seed_;
 };
 

@@ -28,12 +28,15 @@ SCENES = {  # name: (config, width, height, spp, use_bvh)
     "emissive": ("config_c3.yml", 64, 36, 8, 1),
     "clown": ("config_c3.yml", 64, 36, 8, 1),
     "two_balls": ("config_c1.yml", 64, 36, 8, 1),
+    # the procedural scene of scene/random.rs (485 spheres, 383 of them moving) at seed 1
+    "random": ("config_c1.yml", 64, 36, 8, 1),
 }
 
 
 def load(host, name):
     cfg, w, h, spp, use_bvh = SCENES[name]
-    s = host.Session(os.path.join(ROOT, "scenes", cfg), scene=os.path.join(ROOT, "scenes", name + ".yml"))
+    scene = "random" if name == "random" else os.path.join(ROOT, "scenes", name + ".yml")
+    s = host.Session(os.path.join(ROOT, "scenes", cfg), scene=scene)
     p = s.params
     p.width, p.height, p.samples = w, h, spp
     return s, p, use_bvh

@@ -236,9 +236,8 @@ def test_missing_image_and_missing_files(host, tmp_path):
     with pytest.raises(host.HostError) as e:
         host.Session(cfg, scene="noextension")
     assert e.value.code == 10
-    with pytest.raises(host.HostError) as e:
-        host.Session(cfg, scene="random")
-    assert e.value.code == abi.RT_ERR_UNSUPPORTED
+    # "random" and "sandbox" name the reference's built-in loaders (config.rs:39-42)
+    assert host.Session(cfg, scene="random").desc.n_primitives > 400
 
 
 def test_cli_flags_and_exit_codes(tmp_path):
