@@ -19,7 +19,7 @@ extern "C" hipError_t rtdev_launch_trace(const rtdev::TraceArgs *args, int prims
 extern "C" hipError_t rtdev_launch_resolve(const double *accum, double *out, int width, int height,
                                            int strip_rows, int strip_count, int strip_index, int samples,
                                            hipStream_t stream);
-extern "C" int rtdev_pool_blocks_per_cu(int prims_class, int textured, int specular, int bvh);
+extern "C" int rtdev_pool_blocks_per_cu(int prims_class, int textured, int specular, int bvh, size_t dyn_lds);
 extern "C" hipError_t rtdev_launch_trace_pool(const rtdev::TraceArgs *args, int prims_class, int textured, int specular,
                                               int bvh, unsigned blocks, hipStream_t stream);
 extern "C" hipError_t rtdev_launch_resolve_chunks(const double *partial, double *out, int width, int height, int n_chunks,
@@ -81,6 +81,7 @@ struct RtScene {
     DevBuf<rtdev::BvhNode> bvh_nodes;
     DevBuf<int32_t> bvh_prim_index;
     int n_bvh_nodes = 0;
+    bool bvh_nodes_in_lds = false; // node array (64 B each) staged in dynamic LDS when <= 32 KiB
 
     // pooled kernel (default): persistent grid = CUs x resident blocks of the variant
     bool use_v1 = false;   // env RT_TRACE_KERNEL=v1: the lane-per-pixel kernel
@@ -233,6 +234,7 @@ void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtd
     a.bvh_nodes = s->bvh_nodes.ptr;
     a.bvh_prim_index = s->bvh_prim_index.ptr;
     a.n_bvh_nodes = s->n_bvh_nodes;
+    a.bvh_lds_nodes = s->bvh_nodes_in_lds ? s->n_bvh_nodes : 0;
 }
 
 // Enqueue trace (in sample batches, polling `cancel` between them) + resolve.
@@ -501,6 +503,10 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
         if ((rc = upload(s->bvh_nodes, bvh.nodes)) != RT_OK) return rc;
         if ((rc = upload(s->bvh_prim_index, bvh.prim_index)) != RT_OK) return rc;
         s->n_bvh_nodes = (int)bvh.nodes.size();
+        // the device table is stored in leaf order, so a leaf is a contiguous run of records
+        std::vector<rtdev::Prim> ordered(prims.size());
+        for (size_t j = 0; j < bvh.prim_index.size(); ++j) ordered[j] = prims[(size_t)bvh.prim_index[j]];
+        prims.swap(ordered);
     }
     if ((rc = upload(s->prims, prims)) != RT_OK) return rc;
     if ((rc = upload(s->textures, textures)) != RT_OK) return rc;
@@ -519,7 +525,10 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     }
     if (const char *k = getenv("RT_TRACE_KERNEL")) s->use_v1 = strcmp(k, "v1") == 0;
     RT_HIP(hipDeviceGetAttribute(&s->num_cus, hipDeviceAttributeMultiprocessorCount, device));
-    s->pool_blocks_per_cu = rtdev_pool_blocks_per_cu(s->prims_class, s->textured, s->specular, s->use_bvh);
+    s->bvh_nodes_in_lds = s->use_bvh && (size_t)s->n_bvh_nodes * sizeof(rtdev::BvhNode) <= 32 * 1024;
+    if (const char *k = getenv("RT_BVH_LDS")) s->bvh_nodes_in_lds = s->bvh_nodes_in_lds && atoi(k) != 0; // developer knob
+    s->pool_blocks_per_cu = rtdev_pool_blocks_per_cu(s->prims_class, s->textured, s->specular, s->use_bvh,
+                                                     s->bvh_nodes_in_lds ? (size_t)s->n_bvh_nodes * sizeof(rtdev::BvhNode) : 0);
     if (const char *k = getenv("RT_POOL_BLOCKS_PER_CU")) // developer knob for occupancy experiments
         if (atoi(k) > 0) s->pool_blocks_per_cu = atoi(k);
     RT_HIP(s->segments.alloc(1));

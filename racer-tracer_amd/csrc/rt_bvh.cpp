@@ -99,14 +99,54 @@ int emit(BvhBuild &out, std::vector<Item> &items, int begin, int end) {
         return me;
     }
     int mid = begin + n / 2;
-    if (axis >= 0)
-        std::nth_element(items.begin() + begin, items.begin() + mid, items.begin() + end,
-                         [axis](const Item &a, const Item &b) {
-                             if (a.centroid[axis] != b.centroid[axis]) return a.centroid[axis] < b.centroid[axis];
-                             return a.prim < b.prim; // deterministic on ties
-                         });
-    else
+    if (axis >= 0) {
+        // Surface-area heuristic, full sweep over the three axes: minimise
+        // area(L) * |L| + area(R) * |R|.  A plain median split is badly wrong when one
+        // primitive dwarfs the rest (the r = 1000 ground sphere of the random scene
+        // dragged a scene-sized box through eight levels); SAH isolates it at the root.
+        auto half_area = [](const double *lo, const double *hi) {
+            double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+            return dx * dy + dy * dz + dz * dx;
+        };
+        double best_cost = DBL_MAX;
+        int best_axis = axis, best_mid = mid;
+        std::vector<double> right_area((size_t)n);
+        for (int ax = 0; ax < 3; ++ax) {
+            std::sort(items.begin() + begin, items.begin() + end, [ax](const Item &a, const Item &b) {
+                if (a.centroid[ax] != b.centroid[ax]) return a.centroid[ax] < b.centroid[ax];
+                return a.prim < b.prim; // deterministic on ties
+            });
+            double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+            for (int i = end - 1; i > begin; --i) { // right_area[k] = area of items[begin + k, end)
+                for (int k = 0; k < 3; ++k) {
+                    lo[k] = std::min(lo[k], items[(size_t)i].mn[k]);
+                    hi[k] = std::max(hi[k], items[(size_t)i].mx[k]);
+                }
+                right_area[(size_t)(i - begin)] = half_area(lo, hi);
+            }
+            double llo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, lhi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+            for (int i = begin; i < end - 1; ++i) {
+                for (int k = 0; k < 3; ++k) {
+                    llo[k] = std::min(llo[k], items[(size_t)i].mn[k]);
+                    lhi[k] = std::max(lhi[k], items[(size_t)i].mx[k]);
+                }
+                int nl = i - begin + 1;
+                double cost = half_area(llo, lhi) * nl + right_area[(size_t)nl] * (n - nl);
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = ax;
+                    best_mid = begin + nl;
+                }
+            }
+        }
+        std::sort(items.begin() + begin, items.begin() + end, [best_axis](const Item &a, const Item &b) {
+            if (a.centroid[best_axis] != b.centroid[best_axis]) return a.centroid[best_axis] < b.centroid[best_axis];
+            return a.prim < b.prim;
+        });
+        mid = best_mid;
+    } else {
         mid = begin + 4;
+    }
     node.first = -1;
     node.count = 0;
     out.nodes[(size_t)me] = node;

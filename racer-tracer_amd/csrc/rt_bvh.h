@@ -5,9 +5,10 @@
 // axis in {x, y} and both children always visited (bvh_node.rs:31-132).  Only
 // its RESULT is part of the contract — the closest hit in [t_min, t_max],
 // topology-free except for exact ties (SURVEY B-15) — so this one is built for
-// the GPU instead: median split on the longest centroid axis, up to four
-// primitives per leaf, nodes stored in depth-first order with a skip link, so
-// a lane walks it with one integer of state and no stack:
+// the GPU instead: surface-area-heuristic splits (full sweep over three axes),
+// up to four primitives per leaf stored contiguously in leaf order, nodes in
+// depth-first order with a skip link, so a lane walks it with one integer of
+// state and no stack:
 //
 //     i = 0;  while (i < n) { if (ray hits node i) { test its primitives (leaf); i = i + 1 or skip } else i = skip[i]; }
 //

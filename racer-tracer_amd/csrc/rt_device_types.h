@@ -111,7 +111,8 @@ struct TraceArgs {
     // BVH (scenes with more primitives than the brute-force loop is good for)
     const BvhNode *bvh_nodes;
     const int32_t *bvh_prim_index;
-    int32_t n_bvh_nodes, _pad_bvh;
+    int32_t n_bvh_nodes;
+    int32_t bvh_lds_nodes; // == n_bvh_nodes when the node array is staged in dynamic LDS, else 0
 };
 
 } // namespace rtdev

@@ -248,35 +248,45 @@ __device__ __forceinline__ bool prim_t(const Prim &P, d3 o, d3 d, d3 inv_d, doub
 // Closest hit through the skip-link BVH (rt_bvh.h): one integer of traversal
 // state per lane, no stack.  Same acceptance rule as the brute-force loop
 // (t in [t_min, best_t], later equal hit wins), so only exact ties can differ.
+//
+// "while-while" shape: every lane first walks inner nodes until it stands on a
+// leaf whose box it hits (or has left the tree), THEN the wave tests leaf
+// primitives together.  Mixing the two in one loop body makes a wave pay the
+// primitive tests on almost every step (measured 1.35 -> see DESIGN.md).
 template <int PRIMS>
-__device__ __forceinline__ void closest_hit_bvh(const TraceArgs &A, d3 o, d3 d, d3 inv_d, double inv_a, double time,
-                                                double t_min, double &best_t, int &best, int &best_aux) {
+__device__ __forceinline__ void closest_hit_bvh(const TraceArgs &A, const BvhNode *nodes, d3 o, d3 d, d3 inv_d,
+                                                double inv_a, double time, double t_min, double &best_t, int &best,
+                                                int &best_aux) {
     int i = 0;
     const int n = A.n_bvh_nodes;
     while (i < n) {
-        const BvhNode *N = &A.bvh_nodes[i];
-        const double ax = (N->mn[0] - o.x) * inv_d.x, bx = (N->mx[0] - o.x) * inv_d.x;
-        const double ay = (N->mn[1] - o.y) * inv_d.y, by = (N->mx[1] - o.y) * inv_d.y;
-        const double az = (N->mn[2] - o.z) * inv_d.z, bz = (N->mx[2] - o.z) * inv_d.z;
-        // fmin/fmax drop NaNs (0 * inf on a slab boundary), which keeps the test conservative
-        const double t_near = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmax(fmin(az, bz), t_min));
-        const double t_far = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmin(fmax(az, bz), best_t));
-        if (t_near <= t_far) {
-            const int count = N->count;
-            const int first = N->first;
-            for (int k = 0; k < count; ++k) {
-                const int pi = A.bvh_prim_index[first + k];
-                double t;
-                int aux;
-                if (prim_t<PRIMS>(A.prims[pi], o, d, inv_d, inv_a, time, t_min, best_t, t, aux)) {
-                    best_t = t;
-                    best = pi;
-                    best_aux = aux;
-                }
+        int count = 0, first = 0;
+        while (i < n) { // descend / skip until a leaf is entered
+            const BvhNode *N = &nodes[i];
+            const double ax = (N->mn[0] - o.x) * inv_d.x, bx = (N->mx[0] - o.x) * inv_d.x;
+            const double ay = (N->mn[1] - o.y) * inv_d.y, by = (N->mx[1] - o.y) * inv_d.y;
+            const double az = (N->mn[2] - o.z) * inv_d.z, bz = (N->mx[2] - o.z) * inv_d.z;
+            // fmin/fmax drop NaNs (0 * inf on a slab boundary), which keeps the test conservative
+            const double t_near = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmax(fmin(az, bz), t_min));
+            const double t_far = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmin(fmax(az, bz), best_t));
+            if (t_near <= t_far) {
+                count = N->count;
+                first = N->first;
+                i = i + 1; // inner: first child; leaf: its skip link is i + 1 as well
+                if (count > 0) break;
+            } else {
+                i = N->skip;
             }
-            i = i + 1; // inner: first child; leaf: its skip link is i + 1 as well
-        } else {
-            i = N->skip;
+        }
+        for (int k = 0; k < count; ++k) { // the leaf's primitives (stored contiguously in leaf order)
+            const int pi = first + k;
+            double t;
+            int aux;
+            if (prim_t<PRIMS>(A.prims[pi], o, d, inv_d, inv_a, time, t_min, best_t, t, aux)) {
+                best_t = t;
+                best = pi;
+                best_aux = aux;
+            }
         }
     }
 }

@@ -148,6 +148,18 @@ __global__ __launch_bounds__(256, TEXTURED ? 3 : (BVH ? 4 : 5)) void k_trace_poo
         }
         __syncthreads();
     }
+    // BVH nodes are staged in dynamic LDS when they fit (the host sets bvh_lds_nodes and
+    // the launch's dynamic size): a traversal step is a dependent load, and ~100 steps at
+    // L2 latency with 3-4 waves per SIMD is what bounds the big-scene variants.
+    extern __shared__ __align__(16) unsigned char dyn_lds[];
+    const BvhNode *lds_nodes = nullptr;
+    if (BVH && A.bvh_lds_nodes > 0) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(A.bvh_nodes);
+        uint4 *dst = reinterpret_cast<uint4 *>(dyn_lds);
+        for (int i = threadIdx.x; i < A.bvh_lds_nodes * 4; i += 256) dst[i] = src[i];
+        lds_nodes = reinterpret_cast<const BvhNode *>(dyn_lds);
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     WaveLds &L = lds_all[threadIdx.x >> 6];
     unsigned int n_segments = 0;
@@ -267,7 +279,10 @@ __global__ __launch_bounds__(256, TEXTURED ? 3 : (BVH ? 4 : 5)) void k_trace_poo
                     const d3 inv_d = rcp3(d);
                     const double inv_a = PRIMS == PRIMS_RECTS ? 0.0 : rcp_f64(len2(d));
                     if (BVH) {
-                        closest_hit_bvh<PRIMS>(A, o, d, inv_d, inv_a, ray_time, 0.001, best_t, best, best_aux);
+                        if (lds_nodes != nullptr)
+                            closest_hit_bvh<PRIMS>(A, lds_nodes, o, d, inv_d, inv_a, ray_time, 0.001, best_t, best, best_aux);
+                        else
+                            closest_hit_bvh<PRIMS>(A, A.bvh_nodes, o, d, inv_d, inv_a, ray_time, 0.001, best_t, best, best_aux);
                     } else {
                         for (int i = 0; i < A.n_prims; ++i) {
                             double t;
@@ -426,11 +441,12 @@ namespace {
 // linear closest-hit loop, plus PRIMS_ANY x TEXTURED x SPECULAR with the BVH.
 template <int PRIMS, bool TEXTURED, bool SPECULAR, bool BVH> struct PoolVariant {
     static void launch(const rtdev::TraceArgs &a, unsigned blocks, hipStream_t stream) {
-        hipLaunchKernelGGL((rtdev::k_trace_pool_f64<PRIMS, TEXTURED, SPECULAR, BVH>), dim3(blocks), dim3(256), 0, stream, a);
+        const size_t dyn = BVH ? (size_t)a.bvh_lds_nodes * sizeof(rtdev::BvhNode) : 0;
+        hipLaunchKernelGGL((rtdev::k_trace_pool_f64<PRIMS, TEXTURED, SPECULAR, BVH>), dim3(blocks), dim3(256), dyn, stream, a);
     }
-    static int blocks_per_cu() {
+    static int blocks_per_cu(size_t dyn_lds) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rtdev::k_trace_pool_f64<PRIMS, TEXTURED, SPECULAR, BVH>, 256, 0) != hipSuccess)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rtdev::k_trace_pool_f64<PRIMS, TEXTURED, SPECULAR, BVH>, 256, dyn_lds) != hipSuccess)
             return 1;
         return n < 1 ? 1 : n;
     }
@@ -451,8 +467,9 @@ template <class F> auto dispatch_variant(int prims_class, bool textured, bool sp
 } // namespace
 
 // Resident blocks per CU of the variant (the persistent grid is CUs x this).
-extern "C" int rtdev_pool_blocks_per_cu(int prims_class, int textured, int specular, int bvh) {
-    return dispatch_variant(prims_class, textured != 0, specular != 0, bvh != 0, [](auto v) { return decltype(v)::blocks_per_cu(); });
+extern "C" int rtdev_pool_blocks_per_cu(int prims_class, int textured, int specular, int bvh, size_t dyn_lds) {
+    return dispatch_variant(prims_class, textured != 0, specular != 0, bvh != 0,
+                            [dyn_lds](auto v) { return decltype(v)::blocks_per_cu(dyn_lds); });
 }
 
 extern "C" hipError_t rtdev_launch_trace_pool(const rtdev::TraceArgs *args, int prims_class, int textured, int specular,
