@@ -218,6 +218,27 @@ typedef struct RtRenderParams {
     int32_t _pad;
 } RtRenderParams;
 
+/* ---------------------------------------------------------------- tone map
+ * Flattened `dyn ToneMap` (tone_map.rs:14-16) with the parameters its factory
+ * resolves (tone_map.rs:18-66); matrices are row-major. */
+enum RtToneMapKind {
+    RT_TM_NONE = 0,     /* tone_map/none.rs     */
+    RT_TM_REINHARD = 1, /* tone_map/reinhard.rs : max_white                       */
+    RT_TM_HABLE = 2,    /* tone_map/hable.rs    : hable[6], exposure_bias, linear_white */
+    RT_TM_ACES = 3      /* tone_map/aces.rs     : aces_in, aces_out               */
+};
+
+typedef struct RtToneMap {
+    int32_t kind;
+    int32_t _pad;
+    double max_white;
+    double hable[6]; /* shoulder_strength, linear_strength, linear_angle, toe_strength, toe_numerator, toe_denominator */
+    double exposure_bias;
+    double linear_white;
+    double aces_in[9];
+    double aces_out[9];
+} RtToneMap;
+
 typedef struct RtScene RtScene; /* opaque; owned by the library */
 
 /* Statistics of the last render on a scene (path segments = ray_color
@@ -276,6 +297,23 @@ int rt_render_frame_device(RtScene *scene, const RtCamera *camera,
  * (cpu.rs:55-62). */
 int rt_render(RtScene *scene, const RtCamera *camera, const RtRenderParams *params,
               RtTileCallback callback, void *user, const volatile int *cancel);
+
+/* What the reference does to a finished tile downstream of the renderer, on
+ * the device: ScreenBuffer::update's tone map (image_buffer.rs:147-153) and
+ * SavePng's packing `(c * 255.0) as u32 -> (r << 24 | g << 16 | b << 8 | 255)`
+ * as big-endian bytes (image_action/png.rs:21-31), fused in one pass over a
+ * frame produced by rt_render_frame_device.  rgb_device: n_pixels*3 f64;
+ * rgba_device: n_pixels*4 bytes; mapped_device: n_pixels*3 f64 receiving the
+ * tone-mapped floats, or NULL.  Enqueued on `hip_stream`, no synchronisation.
+ * Arithmetic is unfused IEEE f64, so the bytes equal rth_tone_map +
+ * rth_pack_rgba8 on the host. */
+int rt_post_rgba8_device(RtScene *scene, const RtToneMap *tone_map, const double *rgb_device,
+                         size_t n_pixels, uint8_t *rgba_device, double *mapped_device, void *hip_stream);
+
+/* rt_render_frame + rt_post_rgba8_device + copy: out_rgba is HOST memory,
+ * width*height*4 bytes (what SavePng hashes and encodes). */
+int rt_render_frame_rgba8(RtScene *scene, const RtCamera *camera, const RtRenderParams *params,
+                          const RtToneMap *tone_map, uint8_t *out_rgba);
 
 /* Stats of the most recent render call on this scene (synchronises the
  * stream of that call first). */

@@ -45,6 +45,9 @@ int rth_session_params(const RthSession *s, int preview, RtRenderParams *out);
 int rth_session_image_action(const RthSession *s);
 int rth_session_tone_map_kind(const RthSession *s);
 const char *rth_session_image_output_dir(const RthSession *s); /* NULL when unset */
+/* The session's tone map (scene's, else config's: main.rs:84-86) with its resolved
+ * parameters, in the form rt_post_rgba8_device takes. */
+int rth_session_tone_map(const RthSession *s, RtToneMap *out);
 
 /* ScreenBuffer::update's per-pixel tone map (image_buffer.rs:150) over
  * n_pixels RGB triples; in and out may alias. */

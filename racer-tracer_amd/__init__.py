@@ -93,6 +93,19 @@ class Scene:
                                            C.c_void_p(out_ptr), C.c_void_p(stream or 0)),
               "rt_render_frame_device")
 
+    def render_frame_rgba8(self, camera, params, tone_map):
+        """rt_render_frame_rgba8 -> uint8 [H, W, 4]: render, tone-map and pack on the device."""
+        out = np.zeros((params.height, params.width, 4), dtype=np.uint8)
+        check(lib().rt_render_frame_rgba8(self._h, C.byref(camera), C.byref(params), C.byref(tone_map),
+                                          out.ctypes.data_as(C.POINTER(C.c_uint8))), "rt_render_frame_rgba8")
+        return out
+
+    def post_rgba8_device(self, tone_map, rgb_ptr, n_pixels, rgba_ptr, mapped_ptr=None, stream=None):
+        """rt_post_rgba8_device on device addresses (ints)."""
+        check(lib().rt_post_rgba8_device(self._h, C.byref(tone_map), C.c_void_p(rgb_ptr), n_pixels,
+                                         C.c_void_p(rgba_ptr), C.c_void_p(mapped_ptr or 0), C.c_void_p(stream or 0)),
+              "rt_post_rgba8_device")
+
     def render_tiles(self, camera, params, cancel=None):
         """rt_render -> list of (r, c, width, height, float64 [height, width, 3])."""
         tiles = []

@@ -92,6 +92,15 @@ class RtRenderStats(C.Structure):
                 ("resolve_ms", C.c_double), ("kernel_launches", C.c_int32), ("_pad", C.c_int32)]
 
 
+RT_TM_NONE, RT_TM_REINHARD, RT_TM_HABLE, RT_TM_ACES = 0, 1, 2, 3
+
+
+class RtToneMap(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32), ("max_white", C.c_double),
+                ("hable", C.c_double * 6), ("exposure_bias", C.c_double), ("linear_white", C.c_double),
+                ("aces_in", C.c_double * 9), ("aces_out", C.c_double * 9)]
+
+
 RtTileCallback = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_int32,
                              C.c_int32, C.c_int32)
 
@@ -107,6 +116,10 @@ PROTOTYPES = {
                                          C.POINTER(RtRenderParams), C.c_void_p, C.c_void_p]),
     "rt_render": (C.c_int, [C.c_void_p, C.POINTER(RtCamera), C.POINTER(RtRenderParams),
                             RtTileCallback, C.c_void_p, C.POINTER(C.c_int)]),
+    "rt_post_rgba8_device": (C.c_int, [C.c_void_p, C.POINTER(RtToneMap), C.c_void_p, C.c_size_t, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
+    "rt_render_frame_rgba8": (C.c_int, [C.c_void_p, C.POINTER(RtCamera), C.POINTER(RtRenderParams),
+                                        C.POINTER(RtToneMap), C.POINTER(C.c_uint8)]),
     "rt_scene_last_stats": (C.c_int, [C.c_void_p, C.POINTER(RtRenderStats)]),
     "rt_strerror": (C.c_char_p, [C.c_int]),
     "rt_last_error_message": (C.c_char_p, []),

@@ -19,6 +19,8 @@ extern "C" hipError_t rtdev_launch_trace(const rtdev::TraceArgs *args, int prims
 extern "C" hipError_t rtdev_launch_resolve(const double *accum, double *out, int width, int height,
                                            int strip_rows, int strip_count, int strip_index, int samples,
                                            hipStream_t stream);
+extern "C" hipError_t rtdev_launch_post_rgba8(const RtToneMap *tm, const double *rgb, size_t n_pixels, uint8_t *rgba,
+                                              double *mapped, hipStream_t stream);
 extern "C" int rtdev_pool_blocks_per_cu(int prims_class, int textured, int specular, int bvh, size_t dyn_lds);
 extern "C" hipError_t rtdev_launch_trace_pool(const rtdev::TraceArgs *args, int prims_class, int textured, int specular,
                                               int bvh, unsigned blocks, hipStream_t stream);
@@ -92,6 +94,7 @@ struct RtScene {
 
     DevBuf<double> accum;  // running sums, W*H*3 (v1 kernel)
     DevBuf<double> frame;  // resolved frame for the host-output entry points
+    DevBuf<uint8_t> rgba;  // packed frame of rt_render_frame_rgba8
     DevBuf<unsigned long long> segments;
     hipStream_t stream = nullptr; // used by rt_render_frame / rt_render
     hipEvent_t ev_begin = nullptr, ev_traced = nullptr, ev_resolved = nullptr;
@@ -390,6 +393,7 @@ void rt_scene_destroy(RtScene *s) {
     s->partial.release();
     s->queue.release();
     s->frame.release();
+    s->rgba.release();
     s->segments.release();
     if (s->ev_begin) (void)hipEventDestroy(s->ev_begin);
     if (s->ev_traced) (void)hipEventDestroy(s->ev_traced);
@@ -614,6 +618,33 @@ int rt_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, RtTil
                 memcpy(&tile[(size_t)r * w * 3], &frame[((size_t)(y + r) * p->width + x) * 3], (size_t)w * 3 * sizeof(double));
             callback(user, tile.data(), y, x, w, h);
         }
+    return RT_OK;
+}
+
+int rt_post_rgba8_device(RtScene *s, const RtToneMap *tm, const double *rgb_device, size_t n_pixels,
+                         uint8_t *rgba_device, double *mapped_device, void *hip_stream) {
+    if (!s || !tm || !rgb_device || !rgba_device) return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (tm->kind < RT_TM_NONE || tm->kind > RT_TM_ACES) return fail(RT_ERR_INVALID_ARGUMENT, "unknown tone map kind");
+    RT_HIP(hipSetDevice(s->device));
+    RT_HIP(rtdev_launch_post_rgba8(tm, rgb_device, n_pixels, rgba_device, mapped_device, (hipStream_t)hip_stream));
+    return RT_OK;
+}
+
+int rt_render_frame_rgba8(RtScene *s, const RtCamera *camera, const RtRenderParams *p, const RtToneMap *tm,
+                          uint8_t *out_rgba) {
+    if (!s || !tm || !out_rgba) return fail(RT_ERR_INVALID_ARGUMENT, "scene/tone_map/out is NULL");
+    int rc = check_params(camera, p);
+    if (rc != RT_OK) return rc;
+    RT_HIP(hipSetDevice(s->device));
+    const size_t px = (size_t)p->width * (size_t)p->height;
+    if (s->frame.count < px * 3) RT_HIP(s->frame.alloc(px * 3));
+    if (s->rgba.count < px * 4) RT_HIP(s->rgba.alloc(px * 4));
+    rc = enqueue_render(s, camera, p, s->frame.ptr, s->stream, 0, nullptr);
+    if (rc != RT_OK) return rc;
+    rc = rt_post_rgba8_device(s, tm, s->frame.ptr, px, s->rgba.ptr, nullptr, s->stream);
+    if (rc != RT_OK) return rc;
+    RT_HIP(hipStreamSynchronize(s->stream));
+    RT_HIP(hipMemcpy(out_rgba, s->rgba.ptr, px * 4, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -18,6 +18,7 @@ _PROTOS = {
     "rth_session_image_action": (C.c_int, [C.c_void_p]),
     "rth_session_tone_map_kind": (C.c_int, [C.c_void_p]),
     "rth_session_image_output_dir": (C.c_char_p, [C.c_void_p]),
+    "rth_session_tone_map": (C.c_int, [C.c_void_p, _P(abi.RtToneMap)]),
     "rth_tone_map": (C.c_int, [C.c_void_p, _P(C.c_double), _P(C.c_double), C.c_size_t]),
     "rth_pack_rgba8": (C.c_int, [_P(C.c_double), C.c_size_t, _P(C.c_uint8)]),
     "rth_save_png": (C.c_int, [C.c_void_p, _P(C.c_double), C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_size_t]),
@@ -72,6 +73,8 @@ class Session:
         _check(hlib().rth_session_params(self._h, 1, C.byref(self.preview_params)), "rth_session_params")
         self.image_action = hlib().rth_session_image_action(self._h)
         self.tone_map_name = TONE_MAP_NAMES[hlib().rth_session_tone_map_kind(self._h)]
+        self.tone_map_desc = abi.RtToneMap()
+        _check(hlib().rth_session_tone_map(self._h, C.byref(self.tone_map_desc)), "rth_session_tone_map")
         d = hlib().rth_session_image_output_dir(self._h)
         self.image_output_dir = d.decode() if d is not None else None
 

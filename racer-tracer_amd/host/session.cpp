@@ -116,6 +116,14 @@ const char *rth_session_image_output_dir(const RthSession *s) {
     return s && s->config.image_output_dir ? s->config.image_output_dir->c_str() : nullptr;
 }
 
+int rth_session_tone_map(const RthSession *s, RtToneMap *out) {
+    return guarded([&]() -> int {
+        if (!s || !out) throw TracerError(RT_ERR_INVALID_ARGUMENT, "session/out is NULL");
+        *out = s->tone_map->describe();
+        return RT_OK;
+    });
+}
+
 int rth_tone_map(const RthSession *s, const double *in, double *out, size_t n) {
     return guarded([&]() -> int {
         if (!s || !in || !out) throw TracerError(RT_ERR_INVALID_ARGUMENT, "NULL argument");

@@ -1,5 +1,6 @@
 // tone_map.cpp — see tone_map.h.
 #include "tone_map.h"
+#include <cstring>
 
 namespace rthost {
 
@@ -16,9 +17,40 @@ double Hable::partial(double color, const HableData &d, double toe_angle) { // h
     return ((color * (a * color + c * b) + dd * e) / (color * (a * color + b) + dd * f)) - toe_angle;
 }
 
-Hable::Hable(HableData d, double bias, double linear_white_point) // hable.rs:41-50
-    : data(d), toe_angle(d.toe_numerator / d.toe_denominator), exposure_bias(bias),
-      white_scale(1.0 / partial(linear_white_point, d, d.toe_numerator / d.toe_denominator)) {}
+Hable::Hable(HableData d, double bias, double white_point) // hable.rs:41-50
+    : data(d), toe_angle(d.toe_numerator / d.toe_denominator), exposure_bias(bias), linear_white_point(white_point),
+      white_scale(1.0 / partial(white_point, d, d.toe_numerator / d.toe_denominator)) {}
+
+static RtToneMap blank_tone_map(int kind) {
+    RtToneMap t;
+    memset(&t, 0, sizeof t);
+    t.kind = kind;
+    return t;
+}
+RtToneMap ToneMapNone::describe() const { return blank_tone_map(RT_TM_NONE); }
+RtToneMap Reinhard::describe() const {
+    RtToneMap t = blank_tone_map(RT_TM_REINHARD);
+    t.max_white = max_white;
+    return t;
+}
+RtToneMap Hable::describe() const {
+    RtToneMap t = blank_tone_map(RT_TM_HABLE);
+    const double d[6] = {data.shoulder_strength, data.linear_strength, data.linear_angle,
+                         data.toe_strength, data.toe_numerator, data.toe_denominator};
+    memcpy(t.hable, d, sizeof d);
+    t.exposure_bias = exposure_bias;
+    t.linear_white = linear_white_point;
+    return t;
+}
+RtToneMap Aces::describe() const {
+    RtToneMap t = blank_tone_map(RT_TM_ACES);
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            t.aces_in[3 * r + c] = input_matrix[(size_t)r][c];
+            t.aces_out[3 * r + c] = output_matrix[(size_t)r][c];
+        }
+    return t;
+}
 
 Color Hable::tone_map(const Color &color) const { // hable.rs:72-80
     Color c = color * exposure_bias;
