@@ -149,6 +149,63 @@ def test_cancel_before_start_returns_cancel_event(rt, orc, gpu):
         scene.close()
 
 
+def test_cancel_during_render_returns_ok_without_tiles(rt, orc, gpu):
+    """cpu.rs:55-62: a cancel seen while rendering makes render() return Ok(())
+    with no BufferUpdate written.  The flag is polled between sample batches."""
+    import ctypes as C
+    import threading
+    import time
+    bundle, cam, _ = S.cornell_box()
+    w, h, spp = 1920, 1080, 2048            # ~0.3 s of GPU work in 32 batches
+    camera = S.camera_for(cam, w, h)
+    params = S.abi.render_params(w, h, spp)
+    scene = rt.Scene(bundle)
+    try:
+        scene.render_frame(camera, S.abi.render_params(w, h, 1))   # warm-up (allocations)
+        flag = C.c_int(0)
+        timer = threading.Timer(0.03, lambda: setattr(flag, "value", 1))
+        t0 = time.time()
+        timer.start()
+        tiles = scene.render_tiles(camera, params, cancel=C.pointer(flag))
+        elapsed = time.time() - t0
+        timer.join()
+        assert flag.value == 1 and tiles == []
+        assert elapsed < 0.25                                       # stopped early (a full render takes ~0.3 s + 50 MB copy)
+        # the scene is still usable afterwards
+        flag.value = 0
+        small = S.abi.render_params(64, 36, 4, tiles_w=2, tiles_h=2)
+        assert len(scene.render_tiles(S.camera_for(cam, 64, 36), small, cancel=C.pointer(flag))) == 4
+    finally:
+        scene.close()
+
+
+def test_light_linearity_at_full_size(rt, orc, gpu):
+    """Size-independent property at BASELINE's frame size: every cornell_box path ends in the
+    light or in black, so doubling the light's emission doubles each pixel's radiance sum
+    exactly (a power-of-two scale) — the gamma-encoded frames differ by sqrt(2)."""
+    bundle, cam, _ = S.cornell_box()
+    brighter, _, _ = S.cornell_box()
+    brighter.textures[3].color = S.abi.D3(30.0, 30.0, 30.0)
+    w, h, spp = 1920, 1080, 8
+    camera = S.camera_for(cam, w, h)
+    params = S.abi.render_params(w, h, spp)                   # (depth exhaustion adds white, which does not scale: ~1 % of paths)
+    frames = []
+    for b in (bundle, brighter):
+        scene = rt.Scene(b)
+        try:
+            frames.append(scene.render_frame(camera, params))
+        finally:
+            scene.close()
+    a2, b2 = frames[0] ** 2, frames[1] ** 2
+    lit = a2 > 0
+    assert lit.mean() > 0.1                                    # at 8 spp most in-box pixels are still black
+    white_only = np.isclose(a2, b2) & lit                      # paths that ended by depth exhaustion only
+    scaled = np.isclose(b2, 2.0 * a2, rtol=1e-12, atol=0)
+    mixed = lit & ~scaled & ~white_only                        # pixels mixing both kinds of path ends
+    assert scaled.sum() > 0.5 * lit.sum()
+    assert np.all(b2[mixed] > a2[mixed]) and np.all(b2[mixed] < 2.0 * a2[mixed] * (1 + 1e-12))
+
+
 def test_full_size_properties(rt, orc, gpu):
     """BASELINE config 3 size (1920x1080) at reduced spp: properties that do
     not need the oracle at full size + an oracle check on a row band."""
