@@ -215,7 +215,13 @@ typedef struct RtRenderParams {
     int32_t strip_rows;
     int32_t strip_count;
     int32_t strip_index;
-    int32_t _pad;
+    /* `scale` of the preview renderer (config.rs:81, renderer/cpu_scaled.rs): 0 or 1
+     * = every pixel (CpuRenderer).  scale > 1 = CpuRendererScaled: only the top-left
+     * pixel of each scale_w x scale_h block is traced and the block is filled with it,
+     * where scale_w = largest divisor <= scale of (width / tiles_w) and likewise for
+     * rows (cpu_scaled.rs:18-41); what is left over at the right/bottom edge stays
+     * (0,0,0) (cpu_scaled.rs:50-52).  Not combinable with strips. */
+    int32_t scale;
 } RtRenderParams;
 
 /* ---------------------------------------------------------------- tone map

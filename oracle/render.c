@@ -55,9 +55,53 @@ static int row_owned(const RtRenderParams *p, int row) {
 
 /* cpu.rs:26-71 `raytrace` for one tile; the BufferUpdate write (cpu.rs:64-70)
  * becomes a store into the caller's frame at (r = y, c = x). */
+/* cpu_scaled.rs:18-24 */
+static int get_highest_divdable(int value, int div) {
+    if (div < 1) div = 1;
+    while (value % div != 0) --div;
+    return div;
+}
+
+/* cpu_scaled.rs:45-98 `CpuRendererScaled::raytrace`: trace the top-left pixel of
+ * every scale_w x scale_h block and fill the block with it; pixels of the tile
+ * that no whole block covers keep Vec3::default() (cpu_scaled.rs:52). */
+static void raytrace_tile_scaled(Job *job, const int32_t *tile, int scale_w, int scale_h) {
+    const RtRenderParams *p = job->params;
+    int x0 = tile[0], y0 = tile[1], w = tile[2], h = tile[3];
+    int scaled_width = w / scale_w, scaled_height = h / scale_h;
+    unsigned long long segs = 0;
+    for (int r = 0; r < h; ++r)
+        memset(job->out_rgb + 3 * ((size_t)(y0 + r) * (size_t)p->width + (size_t)x0), 0, sizeof(double) * 3 * (size_t)w);
+    for (int row = 0; row < scaled_height; ++row)
+        for (int column = 0; column < scaled_width; ++column) {
+            int px = x0 + column * scale_w, py = y0 + row * scale_h;
+            double u = orc_pixel_u(p, px, py);
+            double color[3] = { 0.0, 0.0, 0.0 };
+            for (int s = 0; s < p->samples; ++s) {
+                double c[3];
+                int n;
+                orc_sample_radiance_u(job->desc, job->scene, job->camera, p, px, py, s, u, c, &n);
+                color[0] += c[0]; color[1] += c[1]; color[2] += c[2];
+                segs += (unsigned long long)n;
+            }
+            double scale = 1.0 / (double)p->samples;
+            double out[3] = { sqrt(scale * color[0]), sqrt(scale * color[1]), sqrt(scale * color[2]) };
+            for (int sh = 0; sh < scale_h; ++sh)
+                for (int sw = 0; sw < scale_w; ++sw)
+                    memcpy(job->out_rgb + 3 * ((size_t)(py + sh) * (size_t)p->width + (size_t)(px + sw)), out, sizeof out);
+        }
+    atomic_fetch_add(&job->segments, segs);
+}
+
 static void raytrace_tile(Job *job, const int32_t *tile) {
     const RtRenderParams *p = job->params;
     int x0 = tile[0], y0 = tile[1], w = tile[2], h = tile[3];
+    if (p->scale > 1) { /* cpu_scaled.rs:33-41 */
+        int tw = p->tiles_w > 0 ? p->tiles_w : 1, th = p->tiles_h > 0 ? p->tiles_h : 1;
+        raytrace_tile_scaled(job, tile, get_highest_divdable(p->width / tw, p->scale),
+                             get_highest_divdable(p->height / th, p->scale));
+        return;
+    }
     unsigned long long segs = 0;
     for (int row = 0; row < h; ++row) {
         if (!row_owned(p, y0 + row)) continue;

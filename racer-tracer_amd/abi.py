@@ -84,7 +84,7 @@ class RtRenderParams(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("samples", C.c_int32),
                 ("max_depth", C.c_int32), ("tiles_w", C.c_int32), ("tiles_h", C.c_int32),
                 ("seed", C.c_uint64), ("strip_rows", C.c_int32), ("strip_count", C.c_int32),
-                ("strip_index", C.c_int32), ("_pad", C.c_int32)]
+                ("strip_index", C.c_int32), ("scale", C.c_int32)]
 
 
 class RtRenderStats(C.Structure):
@@ -194,6 +194,6 @@ def solid_background(color):
 
 
 def render_params(width, height, samples, max_depth=20, tiles_w=10, tiles_h=10, seed=1,
-                  strip_rows=0, strip_count=0, strip_index=0):
+                  strip_rows=0, strip_count=0, strip_index=0, scale=0):
     return RtRenderParams(width, height, samples, max_depth, tiles_w, tiles_h, seed,
-                          strip_rows, strip_count, strip_index, 0)
+                          strip_rows, strip_count, strip_index, scale)

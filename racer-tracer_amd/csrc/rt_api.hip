@@ -25,8 +25,8 @@ extern "C" int rtdev_pool_blocks_per_cu(int prims_class, int textured, int specu
 extern "C" hipError_t rtdev_launch_trace_pool(const rtdev::TraceArgs *args, int prims_class, int textured, int specular,
                                               int bvh, unsigned blocks, hipStream_t stream);
 extern "C" hipError_t rtdev_launch_resolve_chunks(const double *partial, double *out, int width, int height, int n_chunks,
-                                                  int strip_rows, int strip_count, int strip_index, int samples,
-                                                  hipStream_t stream);
+                                                  int strip_rows, int strip_count, int strip_index, int step_x, int step_y,
+                                                  int cover_w, int cover_h, int samples, hipStream_t stream);
 
 namespace {
 
@@ -178,6 +178,8 @@ int check_params(const RtCamera *camera, const RtRenderParams *p) {
     if (p->samples <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "samples must be positive");
     if (p->max_depth < 0 || p->max_depth >= (1 << 24)) return fail(RT_ERR_INVALID_ARGUMENT, "max_depth out of range");
     if ((uint64_t)p->width * (uint64_t)p->height > 0xFFFFFFFFull) return fail(RT_ERR_INVALID_ARGUMENT, "image too large for the pixel counter");
+    if (p->scale < 0) return fail(RT_ERR_INVALID_ARGUMENT, "scale must not be negative");
+    if (p->scale > 1 && p->strip_count > 1) return fail(RT_ERR_INVALID_ARGUMENT, "the preview scale cannot be combined with strips");
     if (p->strip_count > 1) {
         if (p->strip_rows <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "strip_rows must be positive when strip_count > 1");
         if (p->strip_index < 0 || p->strip_index >= p->strip_count) return fail(RT_ERR_INVALID_ARGUMENT, "strip_index out of range");
@@ -216,6 +218,21 @@ void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtd
         a.strip_index = 0;
         a.owned_rows = p->height;
     }
+    a.step_x = a.step_y = 1;
+    a.cover_w = p->width;
+    a.cover_h = p->height;
+    if (p->scale > 1) { // CpuRendererScaled::new (cpu_scaled.rs:33-41) + raytrace's scaled grid (:50-52)
+        auto highest_divisible = [](int value, int div) { // cpu_scaled.rs:18-24
+            while (value % div != 0) --div;
+            return div;
+        };
+        const int tw = p->tiles_w > 0 ? p->tiles_w : 1, th = p->tiles_h > 0 ? p->tiles_h : 1;
+        a.step_x = highest_divisible(p->width / tw, p->scale);
+        a.step_y = highest_divisible(p->height / th, p->scale);
+        a.cover_w = (p->width / a.step_x) * a.step_x;
+        a.cover_h = (p->height / a.step_y) * a.step_y;
+        a.owned_rows = p->height / a.step_y; // grid rows
+    }
     a.seed_lo = (uint32_t)(p->seed & 0xffffffffull);
     a.seed_hi = (uint32_t)(p->seed >> 32);
     a.inv_width_m1 = 1.0 / (double)(p->width - 1);
@@ -252,6 +269,7 @@ int enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, 
     const int n_batches = (p->samples + batch - 1) / batch;
     int launches = 0;
     if (s->use_v1) {
+        if (p->scale > 1) return fail(RT_ERR_UNSUPPORTED, "the v1 kernel has no preview mode");
         if (s->accum.count < n) RT_HIP(s->accum.alloc(n));
         a.accum = s->accum.ptr;
         RT_HIP(hipMemsetAsync(s->segments.ptr, 0, sizeof(unsigned long long), stream));
@@ -276,7 +294,7 @@ int enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, 
         // measured best over 16..512 on cornell_box / three_balls (items stay short
         // enough for a small end-of-launch tail at 1/8 of a frame per GPU, long
         // enough that an item's own ramp-down is small); at most 64 slices.
-        a.tiles_x = (p->width + 7) / 8;
+        a.tiles_x = (a.cover_w / a.step_x + 7) / 8; // grid cells per row (== width unless previewing)
         a.n_tiles = a.tiles_x * ((a.owned_rows + 7) / 8);
         int chunk_samples = 32;
         const int max_slices = 64 / n_batches > 0 ? 64 / n_batches : 1;
@@ -313,7 +331,8 @@ int enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, 
         }
         RT_HIP(hipEventRecord(s->ev_traced, stream));
         RT_HIP(rtdev_launch_resolve_chunks(s->partial.ptr, out_device, p->width, p->height, chunks_done, a.strip_rows,
-                                           a.strip_count, a.strip_index, p->samples, stream));
+                                           a.strip_count, a.strip_index, a.step_x, a.step_y, a.cover_w, a.cover_h,
+                                           p->samples, stream));
         RT_HIP(hipEventRecord(s->ev_resolved, stream));
         s->last_chunks = chunks_done;
     }
@@ -325,6 +344,8 @@ int enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, 
     for (int r = 0; r < p->height; ++r)
         if (a.strip_count <= 1 || (r / a.strip_rows) % a.strip_count == a.strip_index) ++owned;
     s->last_samples = owned * (uint64_t)p->width * (uint64_t)p->samples;
+    if (p->scale > 1) // preview: one traced pixel per block
+        s->last_samples = (uint64_t)(a.cover_w / a.step_x) * (uint64_t)(a.cover_h / a.step_y) * (uint64_t)p->samples;
     return RT_OK;
 }
 

@@ -108,6 +108,9 @@ struct TraceArgs {
     int32_t tiles_x, n_tiles;    // 8x8 tiles over width x owned_rows
     // cpu.rs:36,40 divide by (W-1) and (H-1); the pooled kernel multiplies by these
     double inv_width_m1, inv_height_m1;
+    // Preview renderer (cpu_scaled.rs): grid cell (gx, gy) is pixel (gx*step_x, gy*step_y);
+    // cover_w = grid width * step_x.  step_x = step_y = 1 and cover_w = width otherwise.
+    int32_t step_x, step_y, cover_w, cover_h;
     // BVH (scenes with more primitives than the brute-force loop is good for)
     const BvhNode *bvh_nodes;
     const int32_t *bvh_prim_index;

@@ -178,12 +178,14 @@ __global__ __launch_bounds__(256, TEXTURED ? 3 : (BVH ? 4 : 5)) void k_trace_poo
         const int n_smp = min(A.chunk_samples, A.sample_end - smp0);
 
         // ---- this lane's pixel of the tile (used for the pool table and the final store)
-        const int my_px = tx * 8 + (lane & 7);
+        // (step_x/step_y > 1: the preview renderer, cpu_scaled.rs — the grid cell is the
+        // top-left pixel of a block, the resolve pass fills the block)
+        const int my_px = (tx * 8 + (lane & 7)) * A.step_x;
         const int my_vrow = ty * 8 + (lane >> 3);
-        int my_py = my_vrow;
+        int my_py = my_vrow * A.step_y;
         if (A.strip_count > 1)
             my_py = ((my_vrow / A.strip_rows) * A.strip_count + A.strip_index) * A.strip_rows + my_vrow % A.strip_rows;
-        const bool my_valid = my_px < A.width && my_vrow < A.owned_rows && my_py < A.height;
+        const bool my_valid = my_px < A.cover_w && my_vrow < A.owned_rows && my_py < A.height;
         const uint32_t my_pixel = (uint32_t)my_py * (uint32_t)A.width + (uint32_t)my_px;
         const uint64_t valid_mask = __ballot(my_valid);
         const int n_valid = __popcll(valid_mask);
@@ -232,9 +234,9 @@ __global__ __launch_bounds__(256, TEXTURED ? 3 : (BVH ? 4 : 5)) void k_trace_poo
                         s_off = (int)(w / (uint32_t)n_valid);
                         pix = L.pix_of[w - (uint32_t)s_off * (uint32_t)n_valid];
                     }
-                    const int px = tx * 8 + (pix & 7);
+                    const int px = (tx * 8 + (pix & 7)) * A.step_x;
                     const int vrow = ty * 8 + (pix >> 3);
-                    py = vrow;
+                    py = vrow * A.step_y;
                     if (A.strip_count > 1)
                         py = ((vrow / A.strip_rows) * A.strip_count + A.strip_index) * A.strip_rows + vrow % A.strip_rows;
                     rng.pixel = (uint32_t)py * (uint32_t)A.width + (uint32_t)px;
@@ -418,18 +420,28 @@ __global__ __launch_bounds__(256, TEXTURED ? 3 : (BVH ? 4 : 5)) void k_trace_poo
 }
 
 // vec3.rs:119-125 scale_sqrt over the owned rows: out = sqrt(sum over chunks / samples),
-// chunks added in index order.
+// chunks added in index order.  With step_x/step_y > 1 (preview renderer) every pixel takes
+// the value of its block's top-left pixel and pixels outside the covered area are (0,0,0)
+// (cpu_scaled.rs:50-52, :80-89).
 __global__ __launch_bounds__(256) void k_resolve_chunks_f64(const double *__restrict__ partial, double *__restrict__ out,
                                                             int width, int height, int n_chunks, int strip_rows,
-                                                            int strip_count, int strip_index, double scale) {
+                                                            int strip_count, int strip_index, int step_x, int step_y,
+                                                            int cover_w, int cover_h, double scale) {
     const size_t n = (size_t)width * (size_t)height * 3;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        if (strip_count > 1) {
-            const int row = (int)(i / ((size_t)width * 3));
-            if ((row / strip_rows) % strip_count != strip_index) continue;
+        size_t src = i;
+        if (strip_count > 1 || step_x > 1 || step_y > 1) {
+            const size_t pixel = i / 3;
+            const int row = (int)(pixel / (size_t)width), col = (int)(pixel - (size_t)row * (size_t)width);
+            if (strip_count > 1 && (row / strip_rows) % strip_count != strip_index) continue;
+            if (col >= cover_w || row >= cover_h) {
+                out[i] = 0.0;
+                continue;
+            }
+            src = ((size_t)(row - row % step_y) * (size_t)width + (size_t)(col - col % step_x)) * 3 + (i - pixel * 3);
         }
         double acc = 0.0;
-        for (int c = 0; c < n_chunks; ++c) acc += partial[(size_t)c * n + i];
+        for (int c = 0; c < n_chunks; ++c) acc += partial[(size_t)c * n + src];
         out[i] = sqrt(scale * acc);
     }
 }
@@ -483,13 +495,14 @@ extern "C" hipError_t rtdev_launch_trace_pool(const rtdev::TraceArgs *args, int 
 }
 
 extern "C" hipError_t rtdev_launch_resolve_chunks(const double *partial, double *out, int width, int height, int n_chunks,
-                                                  int strip_rows, int strip_count, int strip_index, int samples,
-                                                  hipStream_t stream) {
+                                                  int strip_rows, int strip_count, int strip_index, int step_x, int step_y,
+                                                  int cover_w, int cover_h, int samples, hipStream_t stream) {
     size_t n = (size_t)width * (size_t)height * 3;
     unsigned blocks = (unsigned)((n + 255) / 256);
     if (blocks > 4096u) blocks = 4096u;
     if (blocks == 0) return hipSuccess;
     hipLaunchKernelGGL(rtdev::k_resolve_chunks_f64, dim3(blocks), dim3(256), 0, stream, partial, out, width, height,
-                       n_chunks, strip_rows, strip_count, strip_index, 1.0 / (double)samples);
+                       n_chunks, strip_rows, strip_count, strip_index, step_x, step_y, cover_w, cover_h,
+                       1.0 / (double)samples);
     return hipGetLastError();
 }

@@ -104,6 +104,9 @@ int rth_session_params(const RthSession *s, int preview, RtRenderParams *out) {
         out->tiles_w = (int32_t)r.num_threads_width;
         out->tiles_h = (int32_t)r.num_threads_height;
         out->seed = s->seed;
+        // the preview renderer is CpuRendererScaled and reads `scale`; the final one is
+        // CpuRenderer and ignores it (config.rs:203-207, renderer.rs:109-116)
+        out->scale = preview ? (int32_t)r.scale : 0;
         return RT_OK;
     });
 }

@@ -109,3 +109,27 @@ def test_invalid_arguments(orc):
     empty = S.abi.SceneBundle([], [], [], S.abi.sky())
     frame, segs = orc.render(empty.desc, camera, S.abi.render_params(8, 8, 2))
     assert segs == 8 * 8 * 2 and (frame > 0.7).all()     # empty scene: background only (SURVEY B-18)
+
+
+def test_preview_renderer_replicates_block_origins(orc):
+    """cpu_scaled.rs:45-98: with scale > 1 only the top-left pixel of each block is
+    traced (same draws as that pixel in a full render) and the block is filled with it."""
+    bundle, cam, _ = S.three_balls()
+    w, h, spp = 100, 45, 3
+    camera = S.camera_for(cam, w, h)
+    full, _ = orc.render(bundle.desc, camera, S.abi.render_params(w, h, spp, tiles_w=10, tiles_h=5))
+    prev, segs = orc.render(bundle.desc, camera, S.abi.render_params(w, h, spp, tiles_w=10, tiles_h=5, scale=4))
+    # tile 10 x 9: scale_w = largest divisor of 10 that is <= 4 -> 2; scale_h = largest divisor of 9 <= 4 -> 3
+    sw, sh = 2, 3
+    assert np.array_equal(prev[::sh, ::sw], full[::sh, ::sw])
+    for dy in range(sh):
+        for dx in range(sw):
+            assert np.array_equal(prev[dy::sh, dx::sw], prev[::sh, ::sw])
+    assert segs < 0.25 * w * h * spp * 3
+    # a tile grid that does not divide the image: the last column/row tile absorbs the remainder
+    # (cpu.rs:97-109) but only whole blocks are drawn, the rest of the tile stays black (cpu_scaled.rs:50-52)
+    w2, h2 = 103, 47
+    cam2 = S.camera_for(cam, w2, h2)
+    prev2, _ = orc.render(bundle.desc, cam2, S.abi.render_params(w2, h2, spp, tiles_w=10, tiles_h=5, scale=4))
+    assert (prev2[:, 102:] == 0).all() and (prev2[45:, :] == 0).all()     # 103 = 51*2 + 1, 47 = 15*3 + 2
+    assert (prev2[:45, :102] > 0).any()
