@@ -255,6 +255,11 @@ void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtd
     a.bvh_prim_index = s->bvh_prim_index.ptr;
     a.n_bvh_nodes = s->n_bvh_nodes;
     a.bvh_lds_nodes = s->bvh_nodes_in_lds ? s->n_bvh_nodes : 0;
+    for (int k = 0; k < 4; ++k) {
+        char name[16];
+        snprintf(name, sizeof name, "RT_DBG%d", k);
+        if (const char *v = getenv(name)) a.dbg[k] = atoi(v);
+    }
 }
 
 // Enqueue trace (in sample batches, polling `cancel` between them) + resolve.

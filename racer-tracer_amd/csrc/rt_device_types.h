@@ -116,6 +116,7 @@ struct TraceArgs {
     const int32_t *bvh_prim_index;
     int32_t n_bvh_nodes;
     int32_t bvh_lds_nodes; // == n_bvh_nodes when the node array is staged in dynamic LDS, else 0
+    int32_t dbg[4];        // developer knobs (env RT_DBG0..3), 0 in production
 };
 
 } // namespace rtdev

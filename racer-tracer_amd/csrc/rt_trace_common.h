@@ -24,10 +24,23 @@ __device__ __forceinline__ Prim load_prim_uniform(const Prim *table, int i) {
     return p;
 }
 
+// The kernel's own argument block, re-read where it is used.  Camera and
+// background are 41 doubles that only the regeneration and miss blocks read;
+// held in SGPRs across the path loop they are spilled to VGPR lanes and come
+// back one v_readlane at a time (measured: ~80 of ~580 VALU instructions per
+// loop iteration).  Reading them through a laundered kernarg pointer keeps the
+// scalar loads (K$ hits) next to their use instead.
+__device__ __forceinline__ const RT_CONSTANT TraceArgs *kernargs_here() {
+    const RT_CONSTANT TraceArgs *p = (const RT_CONSTANT TraceArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p)); // opaque per use: the loads cannot be hoisted out of the loop
+    return p;
+}
+
 // ------------------------------------------------------------------ vec3
 struct d3 {
     double x, y, z;
 };
+__device__ __forceinline__ d3 ld3(const RT_CONSTANT double *p) { return d3{p[0], p[1], p[2]}; }
 __device__ __forceinline__ d3 mk(double x, double y, double z) { return d3{x, y, z}; }
 __device__ __forceinline__ d3 ld3(const double *p) { return d3{p[0], p[1], p[2]}; }
 __device__ __forceinline__ d3 operator+(d3 a, d3 b) { return d3{a.x + b.x, a.y + b.y, a.z + b.z}; }

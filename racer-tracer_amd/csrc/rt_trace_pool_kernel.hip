@@ -35,6 +35,12 @@
 #include <type_traits>
 #include "rt_trace_common.h"
 
+#ifndef RT_OCC_TEX
+#define RT_OCC_TEX 3
+#endif
+#ifndef RT_OCC_SPEC
+#define RT_OCC_SPEC 5
+#endif
 namespace rtdev {
 
 __device__ __forceinline__ int lane_rank(uint64_t mask) { // set bits of `mask` below this lane
@@ -132,7 +138,7 @@ __device__ __forceinline__ void coop_random_in_unit_disk(bool need, uint32_t pix
 // BVH: closest hit through the skip-link hierarchy instead of the linear loop
 // (instantiated for PRIMS_ANY only; chosen for scenes with many primitives).
 template <int PRIMS, bool TEXTURED, bool SPECULAR, bool BVH>
-__global__ __launch_bounds__(256, TEXTURED ? 3 : (BVH ? 4 : 5)) void k_trace_pool_f64(const TraceArgs A) {
+__global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : (BVH ? 4 : (SPECULAR ? RT_OCC_SPEC : 5))) void k_trace_pool_f64(const TraceArgs A) {
     __shared__ WaveLds lds_all[4];
     // The first Perlin table (9 KB: 256 gradients + permutations) is staged in LDS
     // once per block; the 56 random gradient fetches of a marble lookup then hit
@@ -250,15 +256,17 @@ __global__ __launch_bounds__(256, TEXTURED ? 3 : (BVH ? 4 : 5)) void k_trace_poo
             if (A.cam.lens_radius != 0.0)
                 coop_random_in_unit_disk(fresh, rng.pixel, rng.sample, A.seed_lo, A.seed_hi, lane, L.req, lens_x, lens_y);
             if (fresh) { // cpu.rs:39-40 + camera.rs:326-337
+                const RT_CONSTANT TraceArgs *K = kernargs_here();
                 const u4 bc = rng.block(0, RT_RNG_CAMERA, 0);
-                const double v = ((double)py + u53(bc.a, bc.b)) * A.inv_height_m1;
+                const double v = ((double)py + u53(bc.a, bc.b)) * K->inv_height_m1;
                 const double u = L.u[pix];
-                const d3 offset = ld3(A.cam.right) * (lens_x * A.cam.lens_radius) + ld3(A.cam.up) * (lens_y * A.cam.lens_radius);
-                const d3 co = ld3(A.cam.origin);
+                const double lr = K->cam.lens_radius;
+                const d3 offset = ld3(K->cam.right) * (lens_x * lr) + ld3(K->cam.up) * (lens_y * lr);
+                const d3 co = ld3(K->cam.origin);
                 o = co + offset;
-                d = ld3(A.cam.ulc) + u * ld3(A.cam.horizontal) - v * ld3(A.cam.vertical) - co - offset;
+                d = ld3(K->cam.ulc) + u * ld3(K->cam.horizontal) - v * ld3(K->cam.vertical) - co - offset;
                 // camera.rs:335: the ray's time, second double of the same block (MovingSphere reads it)
-                if (PRIMS == PRIMS_ANY) ray_time = A.cam.time_a + (A.cam.time_b - A.cam.time_a) * u53(bc.c, bc.d);
+                if (PRIMS == PRIMS_ANY) ray_time = K->cam.time_a + (K->cam.time_b - K->cam.time_a) * u53(bc.c, bc.d);
                 T = mk(1.0, 1.0, 1.0);
                 seg = 0;
                 alive = true;
@@ -297,10 +305,11 @@ __global__ __launch_bounds__(256, TEXTURED ? 3 : (BVH ? 4 : 5)) void k_trace_poo
                         }
                     }
                     if (best < 0) { // background_color.rs:27-33 / :45-48
-                        d3 bgc = ld3(A.bg.top);
-                        if (A.bg.kind == RT_BG_SKY) {
+                        const RT_CONSTANT TraceArgs *K = kernargs_here();
+                        d3 bgc = ld3(K->bg.top);
+                        if (K->bg.kind == RT_BG_SKY) {
                             const double t = 0.5 * (d.y * rsqrt_f64(len2(d)) + 1.0);
-                            bgc = (1.0 - t) * ld3(A.bg.top) + t * ld3(A.bg.bottom);
+                            bgc = (1.0 - t) * bgc + t * ld3(K->bg.bottom);
                         }
                         contrib = T * bgc;
                         ended = true;
