@@ -26,7 +26,8 @@ extern "C" hipError_t rtdev_launch_trace_pool(const rtdev::TraceArgs *args, int 
                                               int bvh, unsigned blocks, hipStream_t stream);
 extern "C" hipError_t rtdev_launch_resolve_chunks(const double *partial, double *out, int width, int height, int n_chunks,
                                                   int strip_rows, int strip_count, int strip_index, int step_x, int step_y,
-                                                  int cover_w, int cover_h, int samples, hipStream_t stream);
+                                                  int cover_w, int cover_h, int x0, int x_count, int samples,
+                                                  hipStream_t stream);
 
 namespace {
 
@@ -98,6 +99,11 @@ struct RtScene {
     DevBuf<unsigned long long> segments;
     hipStream_t stream = nullptr; // used by rt_render_frame / rt_render
     hipEvent_t ev_begin = nullptr, ev_traced = nullptr, ev_resolved = nullptr;
+    // rt_render's progressive delivery: two pinned column buffers [height][column width][3]
+    // and the events that say a column's copy has landed
+    double *pinned[2] = {nullptr, nullptr};
+    size_t pinned_count[2] = {0, 0};
+    hipEvent_t ev_column[2] = {nullptr, nullptr};
     hipStream_t last_stream = nullptr;
     bool has_stats = false;
     uint64_t last_samples = 0;
@@ -262,19 +268,28 @@ void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtd
     }
 }
 
+// Column window of a progressive render: pixel columns [x0, x0 + width) of every
+// row, `index` of `count` windows of one rt_render call (the segment counter and the
+// begin event belong to the first, the item-counter slots to all of them).
+struct Window {
+    int x0 = 0, width = 0; // width 0 = the whole frame
+    int index = 0, count = 1;
+};
+
 // Enqueue trace (in sample batches, polling `cancel` between them) + resolve.
 // Returns RT_ERR_CANCEL_EVENT when cancelled (callers map that to RT_OK).
 int enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, double *out_device,
-                   hipStream_t stream, int batch, const volatile int *cancel) {
+                   hipStream_t stream, int batch, const volatile int *cancel, const Window &win = Window()) {
     RT_HIP(hipSetDevice(s->device));
     size_t n = (size_t)p->width * (size_t)p->height * 3;
     rtdev::TraceArgs a;
     fill_args(s, camera, p, a);
     if (batch <= 0 || batch > p->samples) batch = p->samples;
-    const int n_batches = (p->samples + batch - 1) / batch;
     int launches = 0;
+    const bool windowed = win.width > 0;
     if (s->use_v1) {
         if (p->scale > 1) return fail(RT_ERR_UNSUPPORTED, "the v1 kernel has no preview mode");
+        if (windowed) return fail(RT_ERR_UNSUPPORTED, "the v1 kernel has no column windows");
         if (s->accum.count < n) RT_HIP(s->accum.alloc(n));
         a.accum = s->accum.ptr;
         RT_HIP(hipMemsetAsync(s->segments.ptr, 0, sizeof(unsigned long long), stream));
@@ -299,24 +314,33 @@ int enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, 
         // measured best over 16..512 on cornell_box / three_balls (items stay short
         // enough for a small end-of-launch tail at 1/8 of a frame per GPU, long
         // enough that an item's own ramp-down is small); at most 64 slices.
-        a.tiles_x = (a.cover_w / a.step_x + 7) / 8; // grid cells per row (== width unless previewing)
+        if (windowed) { // step_x == 1: rt_render never windows a preview
+            a.x_origin = win.x0;
+            a.cover_w = win.x0 + win.width;
+        }
+        a.tiles_x = ((a.cover_w - a.x_origin) / a.step_x + 7) / 8; // grid cells per row of the window
         a.n_tiles = a.tiles_x * ((a.owned_rows + 7) / 8);
         int chunk_samples = 32;
-        const int max_slices = 64 / n_batches > 0 ? 64 / n_batches : 1;
-        if ((batch + chunk_samples - 1) / chunk_samples > max_slices) chunk_samples = (batch + max_slices - 1) / max_slices;
-        if (chunk_samples > batch) chunk_samples = batch;
+        if ((p->samples + chunk_samples - 1) / chunk_samples > 64) chunk_samples = (p->samples + 63) / 64;
         if (const char *k = getenv("RT_POOL_CHUNK")) // developer knob
-            if (atoi(k) > 0) chunk_samples = atoi(k) < batch ? atoi(k) : batch;
-        const int chunks_per_batch = (batch + chunk_samples - 1) / chunk_samples;
-        const int total_chunks = chunks_per_batch * n_batches;
+            if (atoi(k) > 0) chunk_samples = atoi(k);
+        if (chunk_samples > p->samples) chunk_samples = p->samples;
+        // sample batches (cancel polling) are cut on chunk boundaries, so batching changes nothing either
+        batch = (batch + chunk_samples - 1) / chunk_samples * chunk_samples;
+        if (batch > p->samples) batch = p->samples;
+        const int n_batches = (p->samples + batch - 1) / batch;
+        const int total_chunks = (p->samples + chunk_samples - 1) / chunk_samples;
         if (s->partial.count < n * (size_t)total_chunks) RT_HIP(s->partial.alloc(n * (size_t)total_chunks));
-        if (s->queue.count < (size_t)n_batches) RT_HIP(s->queue.alloc((size_t)n_batches));
+        const size_t queue_slots = (size_t)n_batches * (size_t)win.count;
+        if (win.index == 0 && s->queue.count < queue_slots) RT_HIP(s->queue.alloc(queue_slots));
         a.partial = s->partial.ptr;
         a.chunk_samples = chunk_samples;
-        RT_HIP(hipMemsetAsync(s->segments.ptr, 0, sizeof(unsigned long long), stream));
-        RT_HIP(hipMemsetAsync(s->queue.ptr, 0, sizeof(unsigned int) * (size_t)n_batches, stream));
+        if (win.index == 0) {
+            RT_HIP(hipMemsetAsync(s->segments.ptr, 0, sizeof(unsigned long long), stream));
+            RT_HIP(hipMemsetAsync(s->queue.ptr, 0, sizeof(unsigned int) * queue_slots, stream));
+            RT_HIP(hipEventRecord(s->ev_begin, stream));
+        }
         // a slice is only written for the pixels a launch covers; unowned rows are skipped by the resolve
-        RT_HIP(hipEventRecord(s->ev_begin, stream));
         int chunks_done = 0;
         for (int b = 0; b < p->samples; b += batch) {
             if (cancel && *cancel) return RT_ERR_CANCEL_EVENT;
@@ -325,7 +349,7 @@ int enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, 
             a.n_chunks = (a.sample_end - a.sample_begin + chunk_samples - 1) / chunk_samples;
             a.chunk_base = chunks_done;
             a.n_items = (uint32_t)a.n_chunks * (uint32_t)a.n_tiles;
-            a.queue = s->queue.ptr + launches;
+            a.queue = s->queue.ptr + (size_t)win.index * (size_t)n_batches + launches;
             unsigned blocks = (unsigned)(s->num_cus * s->pool_blocks_per_cu);
             unsigned needed = (a.n_items + 3) / 4;
             if (blocks > needed) blocks = needed;
@@ -336,19 +360,21 @@ int enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, 
         }
         RT_HIP(hipEventRecord(s->ev_traced, stream));
         RT_HIP(rtdev_launch_resolve_chunks(s->partial.ptr, out_device, p->width, p->height, chunks_done, a.strip_rows,
-                                           a.strip_count, a.strip_index, a.step_x, a.step_y, a.cover_w, a.cover_h,
-                                           p->samples, stream));
+                                           a.strip_count, a.strip_index, a.step_x, a.step_y,
+                                           windowed ? p->width : a.cover_w, a.cover_h, win.x0, win.width, p->samples,
+                                           stream));
         RT_HIP(hipEventRecord(s->ev_resolved, stream));
         s->last_chunks = chunks_done;
     }
     s->last_stream = stream;
     s->has_stats = true;
-    s->last_launches = launches;
+    s->last_launches = (win.index == 0 ? 0 : s->last_launches) + launches;
     // primary rays traced = owned pixels x samples
     uint64_t owned = 0;
     for (int r = 0; r < p->height; ++r)
         if (a.strip_count <= 1 || (r / a.strip_rows) % a.strip_count == a.strip_index) ++owned;
-    s->last_samples = owned * (uint64_t)p->width * (uint64_t)p->samples;
+    const uint64_t traced = owned * (uint64_t)(windowed ? win.width : p->width) * (uint64_t)p->samples;
+    s->last_samples = (win.index == 0 ? 0 : s->last_samples) + traced;
     if (p->scale > 1) // preview: one traced pixel per block
         s->last_samples = (uint64_t)(a.cover_w / a.step_x) * (uint64_t)(a.cover_h / a.step_y) * (uint64_t)p->samples;
     return RT_OK;
@@ -424,6 +450,10 @@ void rt_scene_destroy(RtScene *s) {
     if (s->ev_begin) (void)hipEventDestroy(s->ev_begin);
     if (s->ev_traced) (void)hipEventDestroy(s->ev_traced);
     if (s->ev_resolved) (void)hipEventDestroy(s->ev_resolved);
+    for (int k = 0; k < 2; ++k) {
+        if (s->ev_column[k]) (void)hipEventDestroy(s->ev_column[k]);
+        if (s->pinned[k]) (void)hipHostFree(s->pinned[k]);
+    }
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -567,6 +597,7 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     RT_HIP(hipEventCreate(&s->ev_begin));
     RT_HIP(hipEventCreate(&s->ev_traced));
     RT_HIP(hipEventCreate(&s->ev_resolved));
+    for (int k = 0; k < 2; ++k) RT_HIP(hipEventCreateWithFlags(&s->ev_column[k], hipEventDisableTiming));
     guard.s = nullptr;
     *out = s;
     return RT_OK;
@@ -610,10 +641,113 @@ int rt_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, RtTil
     if (p->tiles_w <= 0 || p->tiles_h <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "tile grid must be positive");
     if (cancel && *cancel) return RT_ERR_CANCEL_EVENT; // cpu.rs:82-85: prepare_threads fails with CancelEvent
     RT_HIP(hipSetDevice(s->device));
-    size_t n = (size_t)p->width * (size_t)p->height * 3;
+    const size_t n = (size_t)p->width * (size_t)p->height * 3;
     if (s->frame.count < n) RT_HIP(s->frame.alloc(n));
-    // with a cancel flag, trace in batches so the flag is polled about as often
-    // as the reference polls it per tile row (cpu.rs:55)
+    // cpu.rs:73-115 tile grid, column-major, remainders in the last row/column
+    const int width_step = p->width / p->tiles_w, height_step = p->height / p->tiles_h;
+    auto column_x = [&](int ws) { return width_step * ws; };
+    auto column_w = [&](int ws) { return ws == p->tiles_w - 1 ? p->width - width_step * ws : width_step; };
+    // One callback per tile of tile column `ws`, top to bottom; `col` holds the column's
+    // pixels as [height][w][3], so a tile is a contiguous run of it.
+    auto emit_column = [&](int ws, const double *col) {
+        const int x = column_x(ws), w = column_w(ws);
+        for (int hs = 0; hs < p->tiles_h; ++hs) {
+            if (cancel && *cancel) return false;
+            const int y = height_step * hs;
+            const int h = hs == p->tiles_h - 1 ? p->height - y : height_step;
+            if (w <= 0 || h <= 0) continue;
+            callback(user, col + (size_t)y * (size_t)w * 3, y, x, w, h);
+        }
+        return true;
+    };
+
+    // PROGRESSIVE DELIVERY.  The reference's tiles reach the writer as they finish
+    // (cpu.rs:64-70) in roughly column-major order (the order of prepare_threads' list).
+    // Here one tile COLUMN is one unit: trace -> resolve -> copy of column k are enqueued,
+    // then the callbacks of column k-1 run on this thread while the GPU works on column k.
+    // Every pixel's value is independent of the window it was traced in (the RNG is
+    // addressed by the global pixel index, the chunk boundaries depend on spp only), so
+    // the tiles are bit-identical to rt_render_frame's.  The cancel flag is polled before
+    // every launch and every callback; tiles delivered before it rose stay delivered, like
+    // the reference's tiles that finished before the cancel (cpu.rs:55-62).
+    const bool progressive = !s->use_v1 && p->scale <= 1 && p->strip_count <= 1 && p->tiles_w > 1 &&
+                             width_step > 0;
+    if (progressive) {
+        int widest = 0;
+        for (int ws = 0; ws < p->tiles_w; ++ws) widest = column_w(ws) > widest ? column_w(ws) : widest;
+        const size_t col_doubles = (size_t)widest * (size_t)p->height * 3;
+        for (int k = 0; k < 2; ++k)
+            if (s->pinned_count[k] < col_doubles) {
+                if (s->pinned[k]) (void)hipHostFree(s->pinned[k]);
+                s->pinned[k] = nullptr;
+                s->pinned_count[k] = 0;
+                RT_HIP(hipHostMalloc((void **)&s->pinned[k], col_doubles * sizeof(double), hipHostMallocDefault));
+                s->pinned_count[k] = col_doubles;
+            }
+        // with a cancel flag every column is traced in sample batches (about 32 launches per
+        // frame, at least 16 samples each), so a rising flag stops the GPU within one batch
+        int batch = 0;
+        if (cancel) {
+            const int per_column = 32 / p->tiles_w > 0 ? 32 / p->tiles_w : 1;
+            batch = (p->samples + per_column - 1) / per_column;
+            if (batch < 16) batch = 16;
+            if (batch > p->samples) batch = p->samples;
+        }
+        // A pixel's sum depends on the order its samples meet in LDS, i.e. on which 8x8
+        // item tile it sits in.  So the GPU windows are cut on the whole-frame tile grid:
+        // window k = [up8(x_k), up8(x_k+1)) (first from 0, last to the image edge) holds
+        // exactly the item tiles of the whole-frame render, and tile column k is complete
+        // once windows 0..k are (up8(x_k+1) >= x_k+1).  A window may be empty.
+        auto window_begin = [&](int ws) {
+            if (ws <= 0) return 0;
+            if (ws >= p->tiles_w) return p->width;
+            const int x = (column_x(ws) + 7) & ~7;
+            return x < p->width ? x : p->width;
+        };
+        bool cancelled = false;
+        bool started = false; // the first non-empty window resets the counters and records ev_begin
+        int pending = -1;     // column whose copy is in flight
+        for (int ws = 0; ws < p->tiles_w && !cancelled; ++ws) {
+            Window win;
+            win.x0 = window_begin(ws);
+            win.width = window_begin(ws + 1) - win.x0;
+            win.index = started ? ws : 0;
+            win.count = p->tiles_w;
+            if (win.width > 0) {
+                rc = enqueue_render(s, camera, p, s->frame.ptr, s->stream, batch, cancel, win);
+                started = true;
+                if (rc == RT_ERR_CANCEL_EVENT) {
+                    cancelled = true;
+                    break;
+                }
+                if (rc != RT_OK) {
+                    (void)hipStreamSynchronize(s->stream);
+                    return rc;
+                }
+            }
+            const int cx = column_x(ws), cw = column_w(ws);
+            RT_HIP(hipMemcpy2DAsync(s->pinned[ws & 1], (size_t)cw * 3 * sizeof(double), s->frame.ptr + (size_t)cx * 3,
+                                    (size_t)p->width * 3 * sizeof(double), (size_t)cw * 3 * sizeof(double),
+                                    (size_t)p->height, hipMemcpyDeviceToHost, s->stream));
+            RT_HIP(hipEventRecord(s->ev_column[ws & 1], s->stream));
+            if (pending >= 0) { // the previous column is (or soon will be) on the host
+                RT_HIP(hipEventSynchronize(s->ev_column[pending & 1]));
+                if (!emit_column(pending, s->pinned[pending & 1])) cancelled = true;
+            }
+            pending = ws;
+        }
+        if (cancelled) { // cpu.rs:55-62: Ok(()), nothing further is written
+            (void)hipStreamSynchronize(s->stream);
+            return RT_OK;
+        }
+        RT_HIP(hipEventSynchronize(s->ev_column[pending & 1]));
+        emit_column(pending, s->pinned[pending & 1]);
+        return RT_OK;
+    }
+
+    // Whole-frame path (preview scale, strips, a single tile column, the v1 kernel): the
+    // tiles are cut from the finished frame.  With a cancel flag, trace in batches so the
+    // flag is polled about as often as the reference polls it per tile row (cpu.rs:55).
     int batch = 0;
     if (cancel) { // at most 32 launches, at least 16 samples each
         batch = (p->samples + 31) / 32;
@@ -629,21 +763,15 @@ int rt_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, RtTil
     RT_HIP(hipStreamSynchronize(s->stream));
     std::vector<double> frame(n);
     RT_HIP(hipMemcpy(frame.data(), s->frame.ptr, n * sizeof(double), hipMemcpyDeviceToHost));
-    // cpu.rs:73-115 tile grid, column-major, remainders in the last row/column
-    int width_step = p->width / p->tiles_w, height_step = p->height / p->tiles_h;
-    std::vector<double> tile;
-    for (int ws = 0; ws < p->tiles_w; ++ws)
-        for (int hs = 0; hs < p->tiles_h; ++hs) {
-            if (cancel && *cancel) return RT_OK;
-            int x = width_step * ws, y = height_step * hs;
-            int w = ws == p->tiles_w - 1 ? p->width - x : width_step;
-            int h = hs == p->tiles_h - 1 ? p->height - y : height_step;
-            if (w <= 0 || h <= 0) continue;
-            tile.resize((size_t)w * (size_t)h * 3);
-            for (int r = 0; r < h; ++r)
-                memcpy(&tile[(size_t)r * w * 3], &frame[((size_t)(y + r) * p->width + x) * 3], (size_t)w * 3 * sizeof(double));
-            callback(user, tile.data(), y, x, w, h);
-        }
+    std::vector<double> column;
+    for (int ws = 0; ws < p->tiles_w; ++ws) {
+        const int x = column_x(ws), w = column_w(ws);
+        if (w <= 0) continue;
+        column.resize((size_t)w * (size_t)p->height * 3);
+        for (int r = 0; r < p->height; ++r)
+            memcpy(&column[(size_t)r * w * 3], &frame[((size_t)r * p->width + x) * 3], (size_t)w * 3 * sizeof(double));
+        if (!emit_column(ws, column.data())) return RT_OK;
+    }
     return RT_OK;
 }
 

@@ -111,6 +111,9 @@ struct TraceArgs {
     // Preview renderer (cpu_scaled.rs): grid cell (gx, gy) is pixel (gx*step_x, gy*step_y);
     // cover_w = grid width * step_x.  step_x = step_y = 1 and cover_w = width otherwise.
     int32_t step_x, step_y, cover_w, cover_h;
+    // Column window of a progressive render (rt_render): 8x8 tiles start at pixel column x_origin
+    // and pixels at or beyond cover_w are not traced.  0 and `width` for a whole-frame launch.
+    int32_t x_origin;
     // BVH (scenes with more primitives than the brute-force loop is good for)
     const BvhNode *bvh_nodes;
     const int32_t *bvh_prim_index;

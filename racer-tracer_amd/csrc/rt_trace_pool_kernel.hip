@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : (BVH ? 4 : (SPECULAR ?
         // ---- this lane's pixel of the tile (used for the pool table and the final store)
         // (step_x/step_y > 1: the preview renderer, cpu_scaled.rs — the grid cell is the
         // top-left pixel of a block, the resolve pass fills the block)
-        const int my_px = (tx * 8 + (lane & 7)) * A.step_x;
+        const int my_px = A.x_origin + (tx * 8 + (lane & 7)) * A.step_x;
         const int my_vrow = ty * 8 + (lane >> 3);
         int my_py = my_vrow * A.step_y;
         if (A.strip_count > 1)
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : (BVH ? 4 : (SPECULAR ?
                         s_off = (int)(w / (uint32_t)n_valid);
                         pix = L.pix_of[w - (uint32_t)s_off * (uint32_t)n_valid];
                     }
-                    const int px = (tx * 8 + (pix & 7)) * A.step_x;
+                    const int px = A.x_origin + (tx * 8 + (pix & 7)) * A.step_x;
                     const int vrow = ty * 8 + (pix >> 3);
                     py = vrow * A.step_y;
                     if (A.strip_count > 1)
@@ -435,9 +435,17 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : (BVH ? 4 : (SPECULAR ?
 __global__ __launch_bounds__(256) void k_resolve_chunks_f64(const double *__restrict__ partial, double *__restrict__ out,
                                                             int width, int height, int n_chunks, int strip_rows,
                                                             int strip_count, int strip_index, int step_x, int step_y,
-                                                            int cover_w, int cover_h, double scale) {
+                                                            int cover_w, int cover_h, int x0, int x_count,
+                                                            double scale) {
     const size_t n = (size_t)width * (size_t)height * 3;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    // a column window [x0, x0 + x_count) of a progressive render: the grid runs over the window only
+    const size_t n_work = x_count < width ? (size_t)x_count * (size_t)height * 3 : n;
+    for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_work; w += (size_t)gridDim.x * blockDim.x) {
+        size_t i = w;
+        if (x_count < width) {
+            const size_t row = w / ((size_t)x_count * 3);
+            i = (row * (size_t)width + (size_t)x0) * 3 + (w - row * (size_t)x_count * 3);
+        }
         size_t src = i;
         if (strip_count > 1 || step_x > 1 || step_y > 1) {
             const size_t pixel = i / 3;
@@ -505,13 +513,18 @@ extern "C" hipError_t rtdev_launch_trace_pool(const rtdev::TraceArgs *args, int 
 
 extern "C" hipError_t rtdev_launch_resolve_chunks(const double *partial, double *out, int width, int height, int n_chunks,
                                                   int strip_rows, int strip_count, int strip_index, int step_x, int step_y,
-                                                  int cover_w, int cover_h, int samples, hipStream_t stream) {
-    size_t n = (size_t)width * (size_t)height * 3;
+                                                  int cover_w, int cover_h, int x0, int x_count, int samples,
+                                                  hipStream_t stream) {
+    if (x_count <= 0 || x_count > width) {
+        x0 = 0;
+        x_count = width;
+    }
+    size_t n = (size_t)x_count * (size_t)height * 3;
     unsigned blocks = (unsigned)((n + 255) / 256);
     if (blocks > 4096u) blocks = 4096u;
     if (blocks == 0) return hipSuccess;
     hipLaunchKernelGGL(rtdev::k_resolve_chunks_f64, dim3(blocks), dim3(256), 0, stream, partial, out, width, height,
-                       n_chunks, strip_rows, strip_count, strip_index, step_x, step_y, cover_w, cover_h,
+                       n_chunks, strip_rows, strip_count, strip_index, step_x, step_y, cover_w, cover_h, x0, x_count,
                        1.0 / (double)samples);
     return hipGetLastError();
 }

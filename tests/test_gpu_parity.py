@@ -149,32 +149,74 @@ def test_cancel_before_start_returns_cancel_event(rt, orc, gpu):
         scene.close()
 
 
-def test_cancel_during_render_returns_ok_without_tiles(rt, orc, gpu):
-    """cpu.rs:55-62: a cancel seen while rendering makes render() return Ok(())
-    with no BufferUpdate written.  The flag is polled between sample batches."""
+def test_cancel_during_render_returns_ok_and_stops_the_tile_stream(rt, orc, gpu):
+    """cpu.rs:55-62: a cancel seen while rendering makes render() return Ok(());
+    tiles that finished before it stay written, nothing is written afterwards.
+    rt_render delivers tile columns as they finish and polls the flag before
+    every launch (sample batches inside a column) and every callback."""
     import ctypes as C
     import threading
     import time
     bundle, cam, _ = S.cornell_box()
-    w, h, spp = 1920, 1080, 2048            # ~0.3 s of GPU work in 32 batches
+    w, h, spp = 1920, 1080, 2048            # ~0.3 s of GPU work: 10 tile columns x 3 sample batches
     camera = S.camera_for(cam, w, h)
     params = S.abi.render_params(w, h, spp)
     scene = rt.Scene(bundle)
     try:
         scene.render_frame(camera, S.abi.render_params(w, h, 1))   # warm-up (allocations)
         flag = C.c_int(0)
-        timer = threading.Timer(0.03, lambda: setattr(flag, "value", 1))
+        timer = threading.Timer(0.05, lambda: setattr(flag, "value", 1))
         t0 = time.time()
         timer.start()
         tiles = scene.render_tiles(camera, params, cancel=C.pointer(flag))
         elapsed = time.time() - t0
         timer.join()
-        assert flag.value == 1 and tiles == []
-        assert elapsed < 0.25                                       # stopped early (a full render takes ~0.3 s + 50 MB copy)
+        assert flag.value == 1
+        assert len(tiles) < 100                                     # the stream stopped ...
+        assert elapsed < 0.25                                       # ... early (a full render takes ~0.3 s)
+        # what was delivered is a prefix of the column-major tile list (cpu.rs:91-113)
+        expect = [(108 * hs, 192 * ws) for ws in range(10) for hs in range(10)]
+        assert [(t[0], t[1]) for t in tiles] == expect[:len(tiles)]
         # the scene is still usable afterwards
         flag.value = 0
         small = S.abi.render_params(64, 36, 4, tiles_w=2, tiles_h=2)
         assert len(scene.render_tiles(S.camera_for(cam, 64, 36), small, cancel=C.pointer(flag))) == 4
+    finally:
+        scene.close()
+
+
+@pytest.mark.parametrize("w,h,tw,th", [(101, 47, 7, 3), (64, 36, 2, 2), (50, 30, 1, 4), (37, 23, 10, 10), (9, 9, 12, 2)])
+def test_progressive_tiles_are_bit_identical_to_the_frame(rt, orc, gpu, w, h, tw, th):
+    """Tile columns are traced in their own launches (column windows of the item
+    grid) and delivered while the next column renders; every pixel must still be
+    the whole-frame render's pixel bit for bit, in cpu.rs:73-115's order, with and
+    without a cancel flag (the flag adds sample batches inside a column)."""
+    import ctypes as C
+    bundle, cam, _ = S.cornell_box_boxes()
+    spp = 40
+    camera = S.camera_for(cam, w, h)
+    params = S.abi.render_params(w, h, spp, tiles_w=tw, tiles_h=th)
+    scene = rt.Scene(bundle)
+    try:
+        frame = scene.render_frame(camera, params)
+        seg_frame = scene.last_stats().segments
+        for flag in (None, C.c_int(0)):
+            tiles = scene.render_tiles(camera, params, cancel=None if flag is None else C.pointer(flag))
+            st = scene.last_stats()
+            ws_step, hs_step = w // tw, h // th
+            expect = []
+            for ws in range(tw):
+                for hs in range(th):
+                    tile_w = w - ws_step * ws if ws == tw - 1 else ws_step
+                    tile_h = h - hs_step * hs if hs == th - 1 else hs_step
+                    if tile_w > 0 and tile_h > 0:
+                        expect.append((hs_step * hs, ws_step * ws, tile_w, tile_h))
+            assert [t[:4] for t in tiles] == expect
+            stitched = np.full_like(frame, -1.0)
+            for r, c, tile_w, tile_h, arr in tiles:
+                stitched[r:r + tile_h, c:c + tile_w] = arr
+            assert np.array_equal(stitched, frame)
+            assert st.samples == w * h * spp and st.segments == seg_frame
     finally:
         scene.close()
 
