@@ -47,11 +47,19 @@ __device__ __forceinline__ int lane_rank(uint64_t mask) { // set bits of `mask` 
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-struct WaveLds {
-    double u[64];       // cpu.rs:35-36: the per-pixel horizontal jitter, (px + ju) / (W - 1)
+// Per-wave scratch in LDS.  HAS_TIME: the scene has MovingSpheres (PRIMS_ANY variants).
+template <bool HAS_TIME> struct WaveLds {
+    // per pixel of the item's tile: upper_left_corner + u * horizontal with the pixel's ONE
+    // horizontal jitter u = (px + ju) / (W - 1) (cpu.rs:35-36, camera.rs:331)
+    double base[64][3];
     double sum[64][3];  // per-pixel radiance sums of the current item
     uint4 req[64];      // cooperative sampler requests: {pixel, sample, segment, next candidate}
     int pix_of[64];     // pool slot -> lane-order pixel index, for tiles cut by the image edge
+    // Camera samples of the pool entries, drawn 64 entries at a time by the WHOLE wave
+    // (prepare_batch below): entry w sits in slot w & 63 of buffer (w >> 6) & 1.
+    double v[2][64];        // (py + jv) / (H - 1)                      cpu.rs:39-40
+    double lens[2][64][2];  // random_in_unit_disk of the entry        camera.rs:327
+    double time[HAS_TIME ? 2 : 1][HAS_TIME ? 64 : 1]; // ray time      camera.rs:335
 };
 
 // vec3.rs:424-430 for every lane with `need`, evaluated by the whole wave.
@@ -138,8 +146,8 @@ __device__ __forceinline__ void coop_random_in_unit_disk(bool need, uint32_t pix
 // BVH: closest hit through the skip-link hierarchy instead of the linear loop
 // (instantiated for PRIMS_ANY only; chosen for scenes with many primitives).
 template <int PRIMS, bool TEXTURED, bool SPECULAR, bool BVH>
-__global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : (BVH ? 4 : (SPECULAR ? RT_OCC_SPEC : 5))) void k_trace_pool_f64(const TraceArgs A) {
-    __shared__ WaveLds lds_all[4];
+__global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : ((BVH || PRIMS == PRIMS_ANY) ? 4 : (SPECULAR ? RT_OCC_SPEC : 5))) void k_trace_pool_f64(const TraceArgs A) {
+    __shared__ WaveLds<PRIMS == PRIMS_ANY> lds_all[4];
     // The first Perlin table (9 KB: 256 gradients + permutations) is staged in LDS
     // once per block; the 56 random gradient fetches of a marble lookup then hit
     // LDS instead of the vector memory path.
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : (BVH ? 4 : (SPECULAR ?
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
-    WaveLds &L = lds_all[threadIdx.x >> 6];
+    WaveLds<PRIMS == PRIMS_ANY> &L = lds_all[threadIdx.x >> 6];
     unsigned int n_segments = 0;
 
     for (;;) {
@@ -198,7 +206,12 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : (BVH ? 4 : (SPECULAR ?
         {
             PathRng prng{my_pixel, RT_RNG_SAMPLE_PIXEL, A.seed_lo, A.seed_hi};
             u4 bj = prng.block(0, RT_RNG_PIXEL, 0);
-            L.u[lane] = ((double)my_px + u53(bj.a, bj.b)) * A.inv_width_m1; // cpu.rs:35-36
+            const RT_CONSTANT TraceArgs *K = kernargs_here();
+            const double u = ((double)my_px + u53(bj.a, bj.b)) * K->inv_width_m1; // cpu.rs:35-36
+            const d3 base = ld3(K->cam.ulc) + u * ld3(K->cam.horizontal);         // camera.rs:331, first two terms
+            L.base[lane][0] = base.x;
+            L.base[lane][1] = base.y;
+            L.base[lane][2] = base.z;
             L.sum[lane][0] = 0.0;
             L.sum[lane][1] = 0.0;
             L.sum[lane][2] = 0.0;
@@ -206,6 +219,52 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : (BVH ? 4 : (SPECULAR ?
         }
         const uint32_t total = (uint32_t)n_valid * (uint32_t)n_smp; // paths in this item's pool
         uint32_t next = 0;
+        // Pool entry w = (pixel w % n_valid of the tile, sample smp0 + w / n_valid).
+        auto entry_of = [&](uint32_t w, int &pix_out, int &py_out, uint32_t &pixel_out, uint32_t &sample_out) {
+            int s_off;
+            if (n_valid == 64) {
+                pix_out = (int)(w & 63u);
+                s_off = (int)(w >> 6);
+            } else {
+                s_off = (int)(w / (uint32_t)n_valid);
+                pix_out = L.pix_of[w - (uint32_t)s_off * (uint32_t)n_valid];
+            }
+            const int px = A.x_origin + (tx * 8 + (pix_out & 7)) * A.step_x;
+            const int vrow = ty * 8 + (pix_out >> 3);
+            py_out = vrow * A.step_y;
+            if (A.strip_count > 1)
+                py_out = ((vrow / A.strip_rows) * A.strip_count + A.strip_index) * A.strip_rows + vrow % A.strip_rows;
+            pixel_out = (uint32_t)py_out * (uint32_t)A.width + (uint32_t)px;
+            sample_out = (uint32_t)(smp0 + s_off);
+        };
+        // REGENERATION BATCHES.  A lane that starts a new path needs the path's camera
+        // sample: the vertical jitter and ray time (one Philox block) and the lens disk (a
+        // rejection loop).  Only ~16 of 64 lanes start a path in a given iteration, so doing
+        // this at the hand-out runs ~120 instructions at 25 % lane use.  Entries leave the pool
+        // in index order, so the wave instead draws the samples of 64 consecutive entries at
+        // once — every lane busy — into LDS, two batches ahead of `next`.
+        const uint32_t n_batches = (total + 63u) >> 6;
+        uint32_t batches_done = 0;
+        auto prepare_batch = [&](uint32_t b) {
+            const RT_CONSTANT TraceArgs *K = kernargs_here();
+            const uint32_t w = b * 64u + (uint32_t)lane;
+            const bool in_pool = w < total;
+            int pix_b = 0, py_b = 0;
+            uint32_t pixel_b = 0, sample_b = 0;
+            if (in_pool) entry_of(w, pix_b, py_b, pixel_b, sample_b);
+            const u4 bc = philox4x32_10(pixel_b, sample_b, RT_RNG_CAMERA, 0u, A.seed_lo, A.seed_hi);
+            const int buf = (int)(b & 1u);
+            L.v[buf][lane] = ((double)py_b + u53(bc.a, bc.b)) * K->inv_height_m1; // cpu.rs:39-40
+            // camera.rs:335: the ray's time, second double of the same block (MovingSphere reads it)
+            if (PRIMS == PRIMS_ANY) L.time[buf][lane] = K->cam.time_a + (K->cam.time_b - K->cam.time_a) * u53(bc.c, bc.d);
+            // camera.rs:327: aperture 0 multiplies the disk by 0, so its draws are dead and skipped
+            if (K->cam.lens_radius != 0.0) {
+                double lx = 0.0, ly = 0.0;
+                coop_random_in_unit_disk(in_pool, pixel_b, sample_b, A.seed_lo, A.seed_hi, lane, L.req, lx, ly);
+                L.lens[buf][lane][0] = lx;
+                L.lens[buf][lane][1] = ly;
+            }
+        };
 
         // ---- path state of this lane
         bool alive = false;
@@ -224,52 +283,33 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : (BVH ? 4 : (SPECULAR ?
         double fuzz = 0.0;
 
         for (;;) {
+            // ---- camera samples for the entries about to leave the pool (whole wave, see above)
+            while (batches_done < n_batches && batches_done <= (next >> 6) + 1u) prepare_batch(batches_done++);
             // ---- hand pool entries to the lanes without a path (ballot + prefix count)
-            bool fresh = false; // this lane starts a new path in this iteration
-            int py = 0;
             if (next < total) {
                 const uint64_t idle = __ballot(!alive);
                 const uint32_t w = next + (uint32_t)lane_rank(idle);
                 next += (uint32_t)__popcll(idle);
-                if (!alive && w < total) {
-                    int s_off;
-                    if (n_valid == 64) {
-                        pix = (int)(w & 63u);
-                        s_off = (int)(w >> 6);
-                    } else {
-                        s_off = (int)(w / (uint32_t)n_valid);
-                        pix = L.pix_of[w - (uint32_t)s_off * (uint32_t)n_valid];
+                if (!alive && w < total) { // cpu.rs:39-40 + camera.rs:326-337
+                    int py;
+                    entry_of(w, pix, py, rng.pixel, rng.sample);
+                    const RT_CONSTANT TraceArgs *K = kernargs_here();
+                    const int buf = (int)((w >> 6) & 1u), slot = (int)(w & 63u);
+                    const double v = L.v[buf][slot];
+                    const d3 co = ld3(K->cam.origin);
+                    o = co;
+                    d = ld3(L.base[pix]) - v * ld3(K->cam.vertical) - co;
+                    const double lr = K->cam.lens_radius;
+                    if (lr != 0.0) {
+                        const d3 offset = ld3(K->cam.right) * (L.lens[buf][slot][0] * lr) + ld3(K->cam.up) * (L.lens[buf][slot][1] * lr);
+                        o = co + offset;
+                        d = d - offset;
                     }
-                    const int px = A.x_origin + (tx * 8 + (pix & 7)) * A.step_x;
-                    const int vrow = ty * 8 + (pix >> 3);
-                    py = vrow * A.step_y;
-                    if (A.strip_count > 1)
-                        py = ((vrow / A.strip_rows) * A.strip_count + A.strip_index) * A.strip_rows + vrow % A.strip_rows;
-                    rng.pixel = (uint32_t)py * (uint32_t)A.width + (uint32_t)px;
-                    rng.sample = (uint32_t)(smp0 + s_off);
-                    fresh = true;
+                    if (PRIMS == PRIMS_ANY) ray_time = L.time[buf][slot];
+                    T = mk(1.0, 1.0, 1.0);
+                    seg = 0;
+                    alive = true;
                 }
-            }
-            // camera.rs:327: the lens disk of the fresh paths, sampled by the whole wave.
-            // Aperture 0 multiplies the disk by 0, so its draws are dead and skipped.
-            double lens_x = 0.0, lens_y = 0.0;
-            if (A.cam.lens_radius != 0.0)
-                coop_random_in_unit_disk(fresh, rng.pixel, rng.sample, A.seed_lo, A.seed_hi, lane, L.req, lens_x, lens_y);
-            if (fresh) { // cpu.rs:39-40 + camera.rs:326-337
-                const RT_CONSTANT TraceArgs *K = kernargs_here();
-                const u4 bc = rng.block(0, RT_RNG_CAMERA, 0);
-                const double v = ((double)py + u53(bc.a, bc.b)) * K->inv_height_m1;
-                const double u = L.u[pix];
-                const double lr = K->cam.lens_radius;
-                const d3 offset = ld3(K->cam.right) * (lens_x * lr) + ld3(K->cam.up) * (lens_y * lr);
-                const d3 co = ld3(K->cam.origin);
-                o = co + offset;
-                d = ld3(K->cam.ulc) + u * ld3(K->cam.horizontal) - v * ld3(K->cam.vertical) - co - offset;
-                // camera.rs:335: the ray's time, second double of the same block (MovingSphere reads it)
-                if (PRIMS == PRIMS_ANY) ray_time = K->cam.time_a + (K->cam.time_b - K->cam.time_a) * u53(bc.c, bc.d);
-                T = mk(1.0, 1.0, 1.0);
-                seg = 0;
-                alive = true;
             }
             if (__ballot(alive) == 0) break; // pool dry and nothing in flight
 
