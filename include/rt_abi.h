@@ -297,10 +297,16 @@ int rt_render_frame_device(RtScene *scene, const RtCamera *camera,
 
 /* Replaces `CpuRenderer::render` with the reference's own tile stream:
  * tiles_w x tiles_h tiles in column-major order with the last row/column
- * absorbing remainders (cpu.rs:73-115), one callback per tile.  `cancel`
- * (may be NULL) is polled like `do_cancel` (renderer.rs:25-30): when it
- * becomes non-zero the call returns RT_OK without emitting further tiles
- * (cpu.rs:55-62). */
+ * absorbing remainders (cpu.rs:73-115), one callback per tile, on the
+ * calling thread.  Delivery is progressive: a tile column is traced, resolved
+ * and copied while the callbacks of the previous column run, so tiles arrive
+ * during the render as the reference's do (cpu.rs:64-70); their pixels are
+ * bit-identical to rt_render_frame's.  `cancel` (may be NULL) is polled like
+ * `do_cancel` (renderer.rs:25-30) before every launch and every callback: once
+ * it is non-zero the call returns RT_OK and emits nothing further; tiles
+ * delivered before stay delivered (cpu.rs:55-62).  If it is already set on
+ * entry the call returns RT_ERR_CANCEL_EVENT (cpu.rs:82-85).
+ * rt_scene_last_stats after this call: kernel_ms spans all columns. */
 int rt_render(RtScene *scene, const RtCamera *camera, const RtRenderParams *params,
               RtTileCallback callback, void *user, const volatile int *cancel);
 

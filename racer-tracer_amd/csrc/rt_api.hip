@@ -292,7 +292,7 @@ int enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, 
         if (windowed) return fail(RT_ERR_UNSUPPORTED, "the v1 kernel has no column windows");
         if (s->accum.count < n) RT_HIP(s->accum.alloc(n));
         a.accum = s->accum.ptr;
-        RT_HIP(hipMemsetAsync(s->segments.ptr, 0, sizeof(unsigned long long), stream));
+        RT_HIP(hipMemsetAsync(s->segments.ptr, 0, 16 * sizeof(unsigned long long), stream));
         RT_HIP(hipEventRecord(s->ev_begin, stream));
         for (int b = 0; b < p->samples; b += batch) {
             if (cancel && *cancel) return RT_ERR_CANCEL_EVENT;
@@ -336,7 +336,7 @@ int enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, 
         a.partial = s->partial.ptr;
         a.chunk_samples = chunk_samples;
         if (win.index == 0) {
-            RT_HIP(hipMemsetAsync(s->segments.ptr, 0, sizeof(unsigned long long), stream));
+            RT_HIP(hipMemsetAsync(s->segments.ptr, 0, 16 * sizeof(unsigned long long), stream));
             RT_HIP(hipMemsetAsync(s->queue.ptr, 0, sizeof(unsigned int) * queue_slots, stream));
             RT_HIP(hipEventRecord(s->ev_begin, stream));
         }
@@ -591,8 +591,8 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
                                                      s->bvh_nodes_in_lds ? (size_t)s->n_bvh_nodes * sizeof(rtdev::BvhNode) : 0);
     if (const char *k = getenv("RT_POOL_BLOCKS_PER_CU")) // developer knob for occupancy experiments
         if (atoi(k) > 0) s->pool_blocks_per_cu = atoi(k);
-    RT_HIP(s->segments.alloc(1));
-    RT_HIP(hipMemset(s->segments.ptr, 0, sizeof(unsigned long long)));
+    RT_HIP(s->segments.alloc(16)); // [0] = path segments; [1..] = region cycles of a -DRT_PROFILE_REGIONS build
+    RT_HIP(hipMemset(s->segments.ptr, 0, 16 * sizeof(unsigned long long)));
     RT_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     RT_HIP(hipEventCreate(&s->ev_begin));
     RT_HIP(hipEventCreate(&s->ev_traced));
@@ -813,6 +813,18 @@ int rt_scene_last_stats(RtScene *s, RtRenderStats *out) {
     RT_HIP(hipEventElapsedTime(&ms_resolve, s->ev_traced, s->ev_resolved));
     unsigned long long segs = 0;
     RT_HIP(hipMemcpy(&segs, s->segments.ptr, sizeof segs, hipMemcpyDeviceToHost));
+#ifdef RT_PROFILE_REGIONS
+    {
+        unsigned long long c[16];
+        RT_HIP(hipMemcpy(c, s->segments.ptr, sizeof c, hipMemcpyDeviceToHost));
+        static const char *names[10] = {"item setup", "batches", "hand-out + primary ray", "closest hit", "miss/hit/material",
+                                        "sampler", "scatter + accumulate", "item end", "-", "-"};
+        double total = 0;
+        for (int k = 0; k < 10; ++k) total += (double)c[1 + k];
+        for (int k = 0; k < 8; ++k)
+            fprintf(stderr, "region %-24s %6.2f %%  (%.3g wave-cycles)\n", names[k], 100.0 * (double)c[1 + k] / total, (double)c[1 + k]);
+    }
+#endif
     out->samples = s->last_samples;
     out->segments = segs;
     out->kernel_ms = ms_trace;

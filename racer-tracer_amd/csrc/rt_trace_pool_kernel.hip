@@ -43,6 +43,32 @@
 #endif
 namespace rtdev {
 
+// -DRT_PROFILE_REGIONS: developer build that accumulates the shader-clock cycles each wave
+// spends per region of the path loop into A.segments[1..]; rt_scene_last_stats prints them
+// (tools/region_profile.sh).  Not part of the product build.
+#ifdef RT_PROFILE_REGIONS
+#define RT_REGION_DECL                                                          \
+    __shared__ unsigned long long rt_t_all_[4][12];                             \
+    unsigned long long *rt_t_ = rt_t_all_[threadIdx.x >> 6];                    \
+    if ((threadIdx.x & 63) < 11) rt_t_[threadIdx.x & 63] = 0;                   \
+    if ((threadIdx.x & 63) == 11) rt_t_[11] = __builtin_readcyclecounter();
+// usable inside divergent code: the first ACTIVE lane books the time since the previous marker
+#define RT_REGION(k)                                                            \
+    do {                                                                        \
+        if (lane_rank(__ballot(1)) == 0) {                                      \
+            const unsigned long long now_ = __builtin_readcyclecounter();       \
+            rt_t_[k] += now_ - rt_t_[11];                                       \
+            rt_t_[11] = now_;                                                   \
+        }                                                                       \
+    } while (0)
+#define RT_REGION_FLUSH                                                         \
+    if (lane < 10) atomicAdd(A.segments + 1 + lane, rt_t_[lane]);
+#else
+#define RT_REGION_DECL
+#define RT_REGION(k)
+#define RT_REGION_FLUSH
+#endif
+
 __device__ __forceinline__ int lane_rank(uint64_t mask) { // set bits of `mask` below this lane
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
@@ -178,6 +204,7 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : ((BVH || PRIMS == PRIM
     WaveLds<PRIMS == PRIMS_ANY> &L = lds_all[threadIdx.x >> 6];
     unsigned int n_segments = 0;
 
+    RT_REGION_DECL
     for (;;) {
         // ---- next item for this wave
         uint32_t item = 0;
@@ -266,6 +293,7 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : ((BVH || PRIMS == PRIM
             }
         };
 
+        RT_REGION(0); // item setup
         // ---- path state of this lane
         bool alive = false;
         int pix = 0;          // pixel of the tile (lane order) the current path belongs to
@@ -285,6 +313,7 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : ((BVH || PRIMS == PRIM
         for (;;) {
             // ---- camera samples for the entries about to leave the pool (whole wave, see above)
             while (batches_done < n_batches && batches_done <= (next >> 6) + 1u) prepare_batch(batches_done++);
+            RT_REGION(1); // batches
             // ---- hand pool entries to the lanes without a path (ballot + prefix count)
             if (next < total) {
                 const uint64_t idle = __ballot(!alive);
@@ -311,6 +340,7 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : ((BVH || PRIMS == PRIM
                     alive = true;
                 }
             }
+            RT_REGION(2); // hand-out + primary ray
             if (__ballot(alive) == 0) break; // pool dry and nothing in flight
 
             // ---- one ray_color level for every lane with a path
@@ -344,6 +374,7 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : ((BVH || PRIMS == PRIM
                             }
                         }
                     }
+                    RT_REGION(3); // closest hit
                     if (best < 0) { // background_color.rs:27-33 / :45-48
                         const RT_CONSTANT TraceArgs *K = kernargs_here();
                         d3 bgc = ld3(K->bg.top);
@@ -410,6 +441,7 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : ((BVH || PRIMS == PRIM
             // ---- the wave evaluates the open rejection loops together (all 64 lanes arrive
             // here): two rounds settle ~90 % of the requests; the rest resume next iteration,
             // which costs them one idle pass instead of costing the wave a third round
+            RT_REGION(4); // miss / hit record / material
             d3 sph = mk(0.0, 0.0, 0.0);
             if (coop_random_in_unit_sphere(waiting, rng.pixel, rng.sample, seg, cand_base, A.seed_lo, A.seed_hi, lane,
                                            L.req, 2, sph)) {
@@ -417,6 +449,7 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : ((BVH || PRIMS == PRIM
                 finish = true;
             }
 
+            RT_REGION(5); // sampler
             if (finish) {
                 if (is_lambert) { // lambertian.rs:27-33
                     d3 dir = hit_normal + unit_fast(sph);
@@ -451,8 +484,10 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : ((BVH || PRIMS == PRIM
                 atomicAdd(&L.sum[pix][2], contrib.z);
                 alive = false;
             }
+            RT_REGION(6); // scatter + accumulate
         }
 
+        RT_REGION(6); // scatter + accumulate (tail of the last iteration)
         // ---- item done: its sums go to its own slice of `partial`
         if (my_valid) {
             double *dst = A.partial + ((size_t)(A.chunk_base + (int)chunk) * (size_t)A.height * (size_t)A.width + (size_t)my_pixel) * 3;
@@ -462,6 +497,8 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : ((BVH || PRIMS == PRIM
         }
     }
 
+    RT_REGION(7); // item end
+    RT_REGION_FLUSH
     unsigned long long total_segments = n_segments; // one atomic per wave for the statistic
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) total_segments += __shfl_down(total_segments, off, 64);
