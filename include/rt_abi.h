@@ -202,8 +202,8 @@ typedef struct RtCamera {
  * `Image` (image.rs:3-8) + `RenderConfig` (config.rs:75-82) + the seed the
  * reference does not have (util.rs:9-23 is OS-seeded). */
 typedef struct RtRenderParams {
-    int32_t width;      /* screen.width  */
-    int32_t height;     /* screen.height */
+    int32_t width;      /* screen.width  (>= 2: cpu.rs:36 divides by width - 1;   */
+    int32_t height;     /* screen.height  >= 2: cpu.rs:40 divides by height - 1)  */
     int32_t samples;    /* render.samples   */
     int32_t max_depth;  /* render.max_depth */
     int32_t tiles_w;    /* render.num_threads_width  (tile grid of rt_render) */

@@ -180,7 +180,9 @@ template <class T> int upload(DevBuf<T> &buf, const std::vector<T> &host) {
 
 int check_params(const RtCamera *camera, const RtRenderParams *p) {
     if (!camera || !p) return fail(RT_ERR_INVALID_ARGUMENT, "camera/params is NULL");
-    if (p->width <= 0 || p->height <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "width and height must be positive");
+    // cpu.rs:36,40 divide by (W - 1) and (H - 1): a one-pixel dimension is a division by zero in the
+    // reference (inf/NaN rays, an undefined picture); it is refused here instead of imitated
+    if (p->width < 2 || p->height < 2) return fail(RT_ERR_INVALID_ARGUMENT, "width and height must be at least 2");
     if (p->samples <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "samples must be positive");
     if (p->max_depth < 0 || p->max_depth >= (1 << 24)) return fail(RT_ERR_INVALID_ARGUMENT, "max_depth out of range");
     if ((uint64_t)p->width * (uint64_t)p->height > 0xFFFFFFFFull) return fail(RT_ERR_INVALID_ARGUMENT, "image too large for the pixel counter");

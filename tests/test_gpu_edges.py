@@ -1,0 +1,116 @@
+"""GPU edge cases of the render path: degenerate scenes and frame shapes, sample
+counts around the chunk boundaries, bad arguments, and the per-GPU share of
+BASELINE config 5 (cornell_box 3840x2160, 8 GPUs) on one card."""
+import numpy as np
+import pytest
+
+import scenes_py as S
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+TIGHT = 1e-9
+
+
+def _parity(rt, orc, bundle, cam, w, h, spp, tm="None", **kw):
+    camera = S.camera_for(cam, w, h)
+    params = S.abi.render_params(w, h, spp, **kw)
+    ref, ref_segs = orc.render(bundle.desc, camera, params)
+    scene = rt.Scene(bundle)
+    try:
+        got = scene.render_frame(camera, params)
+        stats = scene.last_stats()
+    finally:
+        scene.close()
+    d = np.abs(got - ref)
+    assert np.isfinite(got).all()
+    assert d.max() < TOL
+    assert (d > TIGHT).mean() < 2e-3
+    return got, ref, stats, ref_segs
+
+
+def test_empty_scene_is_the_background(rt, orc, gpu):
+    """No primitives at all: every ray misses (renderer.rs:79-89) - Sky gradient or the
+    solid colour; one segment per sample."""
+    cam = dict(look_from=(0.0, 0.0, 0.0), look_at=(0.0, 0.0, -1.0), vfov=40.0, aperture=0.0, focus_distance=1.0)
+    for bg in (S.abi.sky(), S.abi.solid_background((0.25, 0.5, 0.75))):
+        bundle = S.abi.SceneBundle([], [], [], bg)
+        got, ref, stats, ref_segs = _parity(rt, orc, bundle, cam, 40, 24, 3)
+        assert stats.segments == 40 * 24 * 3 == ref_segs
+    assert np.allclose(got, np.sqrt([0.25, 0.5, 0.75]))  # solid: sqrt(sum / samples) of a constant
+
+
+@pytest.mark.parametrize("w,h", [(2, 2), (9, 2), (2, 9), (3, 64)])
+def test_thin_frames(rt, orc, gpu, w, h):
+    """Two pixels is the smallest regular dimension (u, v in {0 + j, 1 + j} / 1)."""
+    bundle, cam, _ = S.three_balls()
+    _parity(rt, orc, bundle, cam, w, h, 4)
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (1, 8), (8, 1)])
+def test_one_pixel_dimension_is_refused(rt, gpu, w, h):
+    """cpu.rs:36,40 divide by (W-1) and (H-1): with a one-pixel dimension the reference
+    divides by zero (inf/NaN rays).  The device path refuses the frame instead."""
+    bundle, cam, _ = S.two_balls()
+    scene = rt.Scene(bundle)
+    try:
+        with pytest.raises(rt.RtError) as e:
+            scene.render_frame(S.camera_for(cam, 8, 8), S.abi.render_params(w, h, 1))
+        assert e.value.code == S.abi.RT_ERR_INVALID_ARGUMENT
+    finally:
+        scene.close()
+
+
+@pytest.mark.parametrize("spp", [1, 31, 32, 33, 64, 65, 2049])
+def test_sample_counts_around_chunk_boundaries(rt, orc, gpu, spp):
+    """The pooled kernel sums a pixel's samples in chunks of 32 (more above 2048 spp, at most
+    64 slices); any count must give the oracle's frame."""
+    bundle, cam, _ = S.cornell_box()
+    w, h = (16, 9) if spp > 100 else (48, 27)
+    _parity(rt, orc, bundle, cam, w, h, spp)
+
+
+def test_invalid_arguments_are_errors_not_faults(rt, gpu):
+    bundle, cam, _ = S.two_balls()
+    camera = S.camera_for(cam, 16, 9)
+    scene = rt.Scene(bundle)
+    try:
+        for bad in (dict(width=1), dict(height=1), dict(samples=0), dict(max_depth=-1), dict(max_depth=1 << 24),
+                    dict(strip_count=2, strip_rows=0), dict(strip_count=2, strip_rows=8, strip_index=2),
+                    dict(scale=-1)):
+            p = S.abi.render_params(16, 9, 2)
+            for k, v in bad.items():
+                setattr(p, k, v)
+            with pytest.raises(rt.RtError) as e:
+                scene.render_frame(camera, p)
+            assert e.value.code == S.abi.RT_ERR_INVALID_ARGUMENT, bad
+        # and the scene still renders afterwards
+        assert np.isfinite(scene.render_frame(camera, S.abi.render_params(16, 9, 2))).all()
+    finally:
+        scene.close()
+
+
+def test_config5_share_of_one_gpu(rt, orc, gpu):
+    """BASELINE config 5 is cornell_box 3840x2160 on 8 GPUs.  One rank's share (strips of 8
+    rows, every 8th strip) at reduced spp on this card: rows it owns equal the whole-frame
+    render bit for bit, rows it does not own are untouched, the oracle agrees on them."""
+    bundle, cam, _ = S.cornell_box()
+    w, h, spp = 3840, 2160, 2
+    camera = S.camera_for(cam, w, h)
+    scene = rt.Scene(bundle)
+    try:
+        full = scene.render_frame(camera, S.abi.render_params(w, h, spp))
+        for rank in (0, 5):
+            p = S.abi.render_params(w, h, spp, strip_rows=8, strip_count=8, strip_index=rank)
+            part = scene.render_frame(camera, p)
+            st = scene.last_stats()
+            own = ((np.arange(h) // 8) % 8) == rank
+            assert np.array_equal(part[own], full[own])
+            assert (part[~own] == 0).all()
+            assert st.samples == int(own.sum()) * w * spp
+        band = S.abi.render_params(w, h, spp, strip_rows=8, strip_count=270, strip_index=130)   # 8 rows through the box
+        ref, _ = orc.render(bundle.desc, camera, band)
+        rows = ((np.arange(h) // 8) % 270) == 130
+        assert np.abs(ref[rows] - full[rows]).max() < TOL
+    finally:
+        scene.close()
