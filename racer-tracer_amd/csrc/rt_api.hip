@@ -528,6 +528,7 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
             for (int k = 0; k < 3; ++k) q.color[k] = t.color[k];
         }
     }
+    for (rtdev::Prim &q : prims) q.mat = materials[(size_t)q.material];
     std::vector<rtdev::Image> images((size_t)d->n_images);
     s->image_pixels.assign((size_t)d->n_images, nullptr);
     for (int i = 0; i < d->n_images; ++i) {

@@ -1,7 +1,7 @@
 // rt_device_types.h — device-side tables of a scene, as laid out in HBM.
 //
 // These are the upload forms of include/rt_abi.h's PODs: same content,
-// re-packed so that (a) the closest-hit loop reads one 128-byte record per
+// re-packed so that (a) the closest-hit loop reads one 192-byte record per
 // primitive with a wave-uniform index (scalar loads) and (b) what shading
 // needs about a material — kind, fuzz, ior, and the colour when its texture
 // is a plain SolidColor — sits in one record, so the common case costs a
@@ -10,19 +10,6 @@
 #include <stdint.h>
 
 namespace rtdev {
-
-struct alignas(16) Prim { // 128 B
-    double p[6];          // sphere: c.xyz, r | rect: a0,a1,b0,b1,k | box: min.xyz,max.xyz
-    double rot_sin, rot_cos;
-    double tr[3];
-    int32_t kind;         // RtPrimitiveKind
-    int32_t flags;        // RtPrimitiveFlags
-    int32_t material;
-    int32_t _pad0;
-    double inv_radius;    // sphere: 1.0 / radius (sphere.rs:61 divides via reciprocal)
-    double _pad1[2];
-};
-static_assert(sizeof(Prim) == 128, "Prim must be 128 bytes");
 
 struct alignas(16) Material { // 64 B
     int32_t kind;             // RtMaterialKind
@@ -35,6 +22,23 @@ struct alignas(16) Material { // 64 B
     double _pad;
 };
 static_assert(sizeof(Material) == 64, "Material must be 64 bytes");
+
+struct alignas(16) Prim { // 192 B
+    double p[6];          // sphere: c.xyz, r | rect: a0,a1,b0,b1,k | box: min.xyz,max.xyz
+    double rot_sin, rot_cos;
+    double tr[3];
+    int32_t kind;         // RtPrimitiveKind
+    int32_t flags;        // RtPrimitiveFlags
+    int32_t material;
+    int32_t _pad0;
+    double inv_radius;    // sphere: 1.0 / radius (sphere.rs:61 divides via reciprocal)
+    double _pad1[2];
+    // The primitive's material, copied in at upload (scene.rs:74-76: a SceneObject owns its
+    // material): shading the winning primitive is then ONE round of per-lane loads instead of
+    // the dependent chain primitive -> material index -> material record.
+    Material mat;
+};
+static_assert(sizeof(Prim) == 192, "Prim must be 192 bytes");
 
 struct alignas(16) Texture { // 64 B
     int32_t kind;

@@ -430,6 +430,20 @@ __device__ __forceinline__ double sin_lean(double x) {
     return (q & 2) ? -v : v;
 }
 
+// Sign of sin(x) (-1, 0, +1) from sin_lean's own argument reduction: with x = k*pi/2 + r,
+// |r| <= pi/4, sin(x) is sin(r), cos(r), -sin(r), -cos(r) for k mod 4 = 0..3; cos(r) > 0 and
+// sin(r) has the sign of r, so no polynomial is needed.  checkered.rs:36-41 only asks whether
+// the product of three sines is negative.
+__device__ __forceinline__ int sin_sign(double x) {
+    const double kd = rint(x * 0.63661977236758134308); // 2/pi
+    double r = fma(-kd, 1.57079632673412561417e+00, x);
+    r = fma(-kd, 6.07710050630396597660e-11, r);
+    r = fma(-kd, 2.02226624871116645580e-21, r);
+    const int q = (int)kd;
+    const int s = (q & 1) ? 1 : (r > 0.0 ? 1 : (r < 0.0 ? -1 : 0));
+    return (q & 2) ? -s : s;
+}
+
 // Noise through a Perlin table in global memory (scenes with more than one
 // Noise texture; the first table is staged in LDS by the pooled kernel).
 __device__ __forceinline__ double perlin_turbulence_global(const Perlin *pl, d3 p, int depth) {
@@ -442,8 +456,9 @@ __device__ __forceinline__ d3 texture_value_full(const TraceArgs &A, const Perli
                                                  d3 p) {
     const Texture *T = &A.textures[ti];
     if (T->kind == RT_TEX_CHECKERED) { // checkered.rs:32-42
-        const double sines = sin_lean(p.x * 10.0) * sin_lean(p.y * 10.0) * sin_lean(p.z * 10.0);
-        T = &A.textures[sines < 0.0 ? T->tex_odd : T->tex_even];
+        // sines = sin(10x) * sin(10y) * sin(10z) < 0  <=>  an odd number of negative factors, none zero
+        const int sines = sin_sign(p.x * 10.0) * sin_sign(p.y * 10.0) * sin_sign(p.z * 10.0);
+        T = &A.textures[sines < 0 ? T->tex_odd : T->tex_even];
     }
     const int kind = T->kind;
     if (kind == RT_TEX_IMAGE) { // texture/image.rs:28-51

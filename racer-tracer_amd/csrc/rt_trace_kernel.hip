@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_trace_f64(const TraceArgs A) {
                 ended = true;
             } else {
                 const Prim &P = A.prims[best];
-                const Material &M = A.materials[P.material];
+                const Material &M = P.mat;
                 Hit h = prim_hit_record<PRIMS, TEXTURED>(P, o, d, ray_time, best_t, best_aux, M.needs_uv != 0);
                 if (M.kind == RT_MAT_DIFFUSE_LIGHT) { // diffuse_light.rs:25-37
                     contrib = T * texture_value<TEXTURED>(A, nullptr, M, h.u, h.v, h.point);

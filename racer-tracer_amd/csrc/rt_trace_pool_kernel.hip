@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : ((BVH || PRIMS == PRIM
                         ended = true;
                     } else {
                         const Prim &P = A.prims[best];
-                        const Material &M = A.materials[P.material];
+                        const Material &M = P.mat;
                         const Hit h = prim_hit_record<PRIMS, TEXTURED>(P, o, d, ray_time, best_t, best_aux, M.needs_uv != 0);
                         const int kind = M.kind;
                         if (kind == RT_MAT_DIFFUSE_LIGHT) { // diffuse_light.rs:25-37
