@@ -73,6 +73,7 @@ struct RtScene {
     DevBuf<rtdev::Perlin> perlins;
     std::vector<uint8_t *> image_pixels; // device copies of the RGBA8 texels
     int n_prims = 0, n_materials = 0, n_textures = 0, n_images = 0, n_perlins = 0;
+    int perlin_identity = 1; // all permutation tables are the identity (noise.rs:121-130 never shuffles them)
     rtdev::Background bg;
     // kernel specialisation (rt_trace_kernel.hip): 0 rects only, 1 spheres only, 2 anything
     int prims_class = 2;
@@ -207,6 +208,7 @@ void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtd
     a.n_textures = s->n_textures;
     a.n_images = s->n_images;
     a.n_perlins = s->n_perlins;
+    a.perlin_identity = s->perlin_identity;
     a.width = p->width;
     a.height = p->height;
     a.samples = p->samples;
@@ -543,6 +545,8 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     for (int i = 0; i < d->n_perlins; ++i) {
         static_assert(sizeof(rtdev::Perlin) == sizeof(RtPerlin), "Perlin layouts must match");
         memcpy(&perlins[(size_t)i], &d->perlins[i], sizeof(RtPerlin));
+        for (int k = 0; k < 256; ++k)
+            if (d->perlins[i].perm_x[k] != k || d->perlins[i].perm_y[k] != k || d->perlins[i].perm_z[k] != k) s->perlin_identity = 0;
     }
     bool only_rects = true, only_spheres = true;
     for (const rtdev::Prim &q : prims) {

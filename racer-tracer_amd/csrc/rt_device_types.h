@@ -88,6 +88,7 @@ struct TraceArgs {
     const Image *images;
     const Perlin *perlins;
     int32_t n_prims, n_materials, n_textures, n_images, n_perlins;
+    int32_t perlin_identity;     // every Perlin's permutation tables are the identity (always so in the reference)
     int32_t width, height;       // full image
     int32_t samples, max_depth;
     int32_t sample_begin, sample_end; // this launch accumulates samples [begin, end)

@@ -366,6 +366,11 @@ __device__ __forceinline__ Hit prim_hit_record(const Prim &P, d3 o, d3 d, double
 }
 
 // --------------------------------------------------------------- textures
+// IDENTITY: the three permutation tables are the identity.  They always are in the reference —
+// Perlin::permute loops over `(count - 1)..0`, an empty range (noise.rs:121-130, SURVEY B-9) — so
+// rt_scene_create checks the uploaded tables and the lattice hash becomes (i ^ j ^ k) & 255 without
+// three table reads per corner; other tables take the general path.
+template <bool IDENTITY>
 __device__ __forceinline__ double perlin_noise(const Perlin &pl, d3 p) { // noise.rs:57-96
     double fx = floor(p.x), fy = floor(p.y), fz = floor(p.z);
     double u = p.x - fx, v = p.y - fy, w = p.z - fz;
@@ -380,7 +385,11 @@ __device__ __forceinline__ double perlin_noise(const Perlin &pl, d3 p) { // nois
         for (int dj = 0; dj < 2; ++dj)
 #pragma unroll
             for (int dk = 0; dk < 2; ++dk) {
-                int index = pl.perm_x[(uint32_t)(i + di) & 255u] ^ pl.perm_y[(uint32_t)(j + dj) & 255u] ^
+                int index;
+                if (IDENTITY)
+                    index = (i + di) ^ (j + dj) ^ (k + dk);
+                else
+                    index = pl.perm_x[(uint32_t)(i + di) & 255u] ^ pl.perm_y[(uint32_t)(j + dj) & 255u] ^
                             pl.perm_z[(uint32_t)(k + dk) & 255u];
                 const double *g = pl.ranvec[index & 255];
                 d3 weight = mk(u - di, v - dj, w - dk);
@@ -390,10 +399,11 @@ __device__ __forceinline__ double perlin_noise(const Perlin &pl, d3 p) { // nois
     return accum;
 }
 
+template <bool IDENTITY>
 __device__ __forceinline__ double perlin_turbulence(const Perlin &pl, d3 p, int depth) { // noise.rs:98-109
     double accum = 0.0, weight = 1.0;
     for (int o = 0; o < depth; ++o) {
-        accum += weight * perlin_noise(pl, p);
+        accum += weight * perlin_noise<IDENTITY>(pl, p);
         weight *= 0.5;
         p = p * 2.0;
     }
@@ -444,12 +454,6 @@ __device__ __forceinline__ int sin_sign(double x) {
     return (q & 2) ? -s : s;
 }
 
-// Noise through a Perlin table in global memory (scenes with more than one
-// Noise texture; the first table is staged in LDS by the pooled kernel).
-__device__ __forceinline__ double perlin_turbulence_global(const Perlin *pl, d3 p, int depth) {
-    return perlin_turbulence(*pl, p, depth);
-}
-
 // Texture::value for everything that is not a plain SolidColor.
 // lds_perlin: LDS copy of A.perlins[0], or nullptr.
 __device__ __forceinline__ d3 texture_value_full(const TraceArgs &A, const Perlin *lds_perlin, int ti, double u, double v,
@@ -475,9 +479,11 @@ __device__ __forceinline__ d3 texture_value_full(const TraceArgs &A, const Perli
         return mk((double)px.x * s, (double)px.y * s, (double)px.z * s);
     }
     if (kind == RT_TEX_NOISE) { // noise.rs:26-33
+        // The pooled kernel stages the first table's gradients in LDS when the permutations are the
+        // identity (the reference's case); anything else reads its table from global memory.
         double turb;
-        if (lds_perlin != nullptr && T->perlin == 0) turb = perlin_turbulence(*lds_perlin, p, T->depth);
-        else turb = perlin_turbulence_global(&A.perlins[T->perlin], p, T->depth);
+        if (lds_perlin != nullptr && T->perlin == 0) turb = perlin_turbulence<true>(*lds_perlin, p, T->depth);
+        else turb = perlin_turbulence<false>(A.perlins[T->perlin], p, T->depth);
         const double f = 1.0 + sin_lean(T->scale * p.z + 10.0 * turb);
         return (ld3(T->color) * 0.5) * f;
     }

@@ -32,6 +32,7 @@
 //    accepted candidate in stream order.  ~3 rounds instead of ~6.4, identical
 //    values (the accepted candidate is exactly the one the sequential loop
 //    would have stopped at).
+#include <cstddef>
 #include <type_traits>
 #include "rt_trace_common.h"
 
@@ -174,17 +175,22 @@ __device__ __forceinline__ void coop_random_in_unit_disk(bool need, uint32_t pix
 template <int PRIMS, bool TEXTURED, bool SPECULAR, bool BVH>
 __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : ((BVH || PRIMS == PRIMS_ANY) ? 4 : (SPECULAR ? RT_OCC_SPEC : 5))) void k_trace_pool_f64(const TraceArgs A) {
     __shared__ WaveLds<PRIMS == PRIMS_ANY> lds_all[4];
-    // The first Perlin table (9 KB: 256 gradients + permutations) is staged in LDS
-    // once per block; the 56 random gradient fetches of a marble lookup then hit
-    // LDS instead of the vector memory path.
-    __shared__ typename std::conditional<TEXTURED, Perlin, int>::type lds_perlin_storage;
+    // The gradients of the first Perlin table (6 KB) are staged in LDS once per block when the
+    // permutation tables are the identity (always, in the reference: noise.rs:121-130): the 56
+    // random gradient fetches of a marble lookup then hit LDS instead of the vector memory
+    // path, and the lattice hash needs no table.
+    struct PerlinGradients {
+        double ranvec[256][3];
+    };
+    static_assert(offsetof(Perlin, ranvec) == 0, "the gradients lead the Perlin record");
+    __shared__ typename std::conditional<TEXTURED, PerlinGradients, int>::type lds_perlin_storage;
     const Perlin *lds_perlin = nullptr;
     if (TEXTURED) {
-        if (A.n_perlins > 0) {
+        if (A.n_perlins > 0 && A.perlin_identity) {
             const uint64_t *src = reinterpret_cast<const uint64_t *>(A.perlins);
             uint64_t *dst = reinterpret_cast<uint64_t *>(&lds_perlin_storage);
-            for (int i = threadIdx.x; i < (int)(sizeof(Perlin) / 8); i += 256) dst[i] = src[i];
-            lds_perlin = reinterpret_cast<const Perlin *>(&lds_perlin_storage);
+            for (int i = threadIdx.x; i < (int)(sizeof(PerlinGradients) / 8); i += 256) dst[i] = src[i];
+            lds_perlin = reinterpret_cast<const Perlin *>(&lds_perlin_storage); // only .ranvec is read (IDENTITY path)
         }
         __syncthreads();
     }

@@ -114,3 +114,36 @@ def test_config5_share_of_one_gpu(rt, orc, gpu):
         assert np.abs(ref[rows] - full[rows]).max() < TOL
     finally:
         scene.close()
+
+
+def _noise_scene(shuffled):
+    """A marble sphere on a checker ground: Noise texture over a Perlin table whose
+    permutation tables are either the identity (what the reference always has:
+    noise.rs:121-130 never shuffles) or a real permutation (the ABI allows it)."""
+    abi = S.abi
+    rng = np.random.default_rng(7)
+    pl = abi.RtPerlin()
+    g = rng.uniform(-1.0, 1.0, size=(256, 3))
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    for i in range(256):
+        for k in range(3):
+            pl.ranvec[i][k] = float(g[i, k])
+    perms = [rng.permutation(256) if shuffled else np.arange(256) for _ in range(3)]
+    for i in range(256):
+        pl.perm_x[i], pl.perm_y[i], pl.perm_z[i] = int(perms[0][i]), int(perms[1][i]), int(perms[2][i])
+    noise = abi.RtTexture(abi.RT_TEX_NOISE, 0, 0, 0, 0, 7, abi.D3(1.0, 1.0, 1.0), 4.0)
+    checker = abi.RtTexture(abi.RT_TEX_CHECKERED, 2, 3, 0, 0, 0, abi.D3(0, 0, 0), 0.0)
+    textures = [noise, checker, abi.solid((0.2, 0.3, 0.1)), abi.solid((0.9, 0.9, 0.9))]
+    materials = [abi.material(abi.RT_MAT_LAMBERTIAN, 0), abi.material(abi.RT_MAT_LAMBERTIAN, 1)]
+    prims = [abi.sphere((0.0, 2.0, 0.0), 2.0, 0, 1), abi.sphere((0.0, -1000.0, 0.0), 1000.0, 1, 2)]
+    cam = dict(look_from=(13.0, 2.0, 3.0), look_at=(0.0, 0.0, 0.0), vfov=20.0, aperture=0.0, focus_distance=10.0)
+    return abi.SceneBundle(prims, materials, textures, abi.sky(), perlins=[pl]), cam
+
+
+@pytest.mark.parametrize("shuffled", [False, True])
+def test_noise_with_identity_and_shuffled_permutations(rt, orc, gpu, shuffled):
+    """The device hashes the lattice as (i ^ j ^ k) & 255 when every permutation table is the
+    identity and reads the tables otherwise; both must give the oracle's marble."""
+    bundle, cam = _noise_scene(shuffled)
+    got, ref, _, _ = _parity(rt, orc, bundle, cam, 96, 54, 6)
+    assert got.std() > 0.05
