@@ -378,11 +378,16 @@ __device__ __forceinline__ double perlin_noise(const Perlin &pl, d3 p) { // nois
     double uu = u * u * (3.0 - 2.0 * u);
     double vv = v * v * (3.0 - 2.0 * v);
     double ww = w * w * (3.0 - 2.0 * w);
+    // noise.rs:84-91 weights corner (di, dj, dk) with (di*uu + (1-di)*(1-uu)) * (dj*vv + ...) * (dk*ww + ...);
+    // with di in {0, 1} that sum is exactly uu or (1 - uu) (x*1 + y*0 = x for finite y), so the
+    // factors are formed once per axis and multiplied in the same order
+    const double fu[2] = {1.0 - uu, uu}, fv[2] = {1.0 - vv, vv}, fw[2] = {1.0 - ww, ww};
     double accum = 0.0;
 #pragma unroll
     for (int di = 0; di < 2; ++di)
 #pragma unroll
-        for (int dj = 0; dj < 2; ++dj)
+        for (int dj = 0; dj < 2; ++dj) {
+            const double fuv = fu[di] * fv[dj];
 #pragma unroll
             for (int dk = 0; dk < 2; ++dk) {
                 int index;
@@ -393,9 +398,9 @@ __device__ __forceinline__ double perlin_noise(const Perlin &pl, d3 p) { // nois
                             pl.perm_z[(uint32_t)(k + dk) & 255u];
                 const double *g = pl.ranvec[index & 255];
                 d3 weight = mk(u - di, v - dj, w - dk);
-                accum += (di * uu + (1 - di) * (1.0 - uu)) * (dj * vv + (1 - dj) * (1.0 - vv)) *
-                         (dk * ww + (1 - dk) * (1.0 - ww)) * dot(ld3(g), weight);
+                accum += fuv * fw[dk] * dot(ld3(g), weight);
             }
+        }
     return accum;
 }
 
