@@ -311,19 +311,19 @@ int enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, 
                                     a.strip_index, p->samples, stream));
         RT_HIP(hipEventRecord(s->ev_resolved, stream));
     } else {
-        // Work items = 8x8 tiles x sample chunks.  The chunk length depends on the
-        // sample count ONLY (never on tiling, strips or the device), because the
-        // chunk boundaries fix the order in which a pixel's samples are summed: the
-        // frame is then bit-identical for every GPU count.  32 samples per chunk
-        // measured best over 16..512 on cornell_box / three_balls (items stay short
-        // enough for a small end-of-launch tail at 1/8 of a frame per GPU, long
-        // enough that an item's own ramp-down is small); at most 64 slices.
+        // Work items = 8x8 tiles x sample chunks.
         if (windowed) { // step_x == 1: rt_render never windows a preview
             a.x_origin = win.x0;
             a.cover_w = win.x0 + win.width;
         }
         a.tiles_x = ((a.cover_w - a.x_origin) / a.step_x + 7) / 8; // grid cells per row of the window
         a.n_tiles = a.tiles_x * ((a.owned_rows + 7) / 8);
+        // Sample chunks.  Their boundaries fix the order in which a pixel's samples are summed, so
+        // they depend on the sample count ONLY (never on tiling, strips, batches or the device): the
+        // frame is bit-identical for every GPU count.  32 samples per chunk measured best over
+        // 16..512 on cornell_box / three_balls (more above 2048 spp: at most 64 slices).  Finer
+        // chunks for the last samples were tried against the end-of-launch tail and lost: the last
+        // wave ends only 0.34 ms after the first (C3), and small items cost more than that in ramps.
         int chunk_samples = 32;
         if ((p->samples + chunk_samples - 1) / chunk_samples > 64) chunk_samples = (p->samples + 63) / 64;
         if (const char *k = getenv("RT_POOL_CHUNK")) // developer knob
@@ -341,6 +341,10 @@ int enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, 
         a.chunk_samples = chunk_samples;
         if (win.index == 0) {
             RT_HIP(hipMemsetAsync(s->segments.ptr, 0, 16 * sizeof(unsigned long long), stream));
+#ifdef RT_PROFILE_REGIONS
+            RT_HIP(hipMemsetAsync(s->segments.ptr + 11, 0xff, sizeof(unsigned long long), stream)); // min slots
+            RT_HIP(hipMemsetAsync(s->segments.ptr + 13, 0xff, sizeof(unsigned long long), stream));
+#endif
             RT_HIP(hipMemsetAsync(s->queue.ptr, 0, sizeof(unsigned int) * queue_slots, stream));
             RT_HIP(hipEventRecord(s->ev_begin, stream));
         }
@@ -830,6 +834,9 @@ int rt_scene_last_stats(RtScene *s, RtRenderStats *out) {
         for (int k = 0; k < 10; ++k) total += (double)c[1 + k];
         for (int k = 0; k < 8; ++k)
             fprintf(stderr, "region %-24s %6.2f %%  (%.3g wave-cycles)\n", names[k], 100.0 * (double)c[1 + k] / total, (double)c[1 + k]);
+        // 100 MHz wall clock: when did the first/last wave start and end (last launch of the call)
+        fprintf(stderr, "waves: last start +%.3f ms, first end +%.3f ms, last end +%.3f ms after the first start\n",
+                (double)(c[12] - c[11]) * 1e-5, (double)(c[13] - c[11]) * 1e-5, (double)(c[14] - c[11]) * 1e-5);
     }
 #endif
     out->samples = s->last_samples;

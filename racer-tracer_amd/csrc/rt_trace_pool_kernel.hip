@@ -52,7 +52,8 @@ namespace rtdev {
     __shared__ unsigned long long rt_t_all_[4][12];                             \
     unsigned long long *rt_t_ = rt_t_all_[threadIdx.x >> 6];                    \
     if ((threadIdx.x & 63) < 11) rt_t_[threadIdx.x & 63] = 0;                   \
-    if ((threadIdx.x & 63) == 11) rt_t_[11] = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63) == 11) rt_t_[11] = __builtin_readcyclecounter();   \
+    const unsigned long long rt_wave_start_ = wall_clock64();
 // usable inside divergent code: the first ACTIVE lane books the time since the previous marker
 #define RT_REGION(k)                                                            \
     do {                                                                        \
@@ -63,7 +64,14 @@ namespace rtdev {
         }                                                                       \
     } while (0)
 #define RT_REGION_FLUSH                                                         \
-    if (lane < 10) atomicAdd(A.segments + 1 + lane, rt_t_[lane]);
+    if (lane < 10) atomicAdd(A.segments + 1 + lane, rt_t_[lane]);               \
+    if (lane == 0) { /* wall clock (100 MHz) of the first/last wave start and end */ \
+        const unsigned long long end_ = wall_clock64();                         \
+        atomicMin(A.segments + 11, rt_wave_start_);                             \
+        atomicMax(A.segments + 12, rt_wave_start_);                             \
+        atomicMin(A.segments + 13, end_);                                       \
+        atomicMax(A.segments + 14, end_);                                       \
+    }
 #else
 #define RT_REGION_DECL
 #define RT_REGION(k)
