@@ -110,7 +110,7 @@ void idct_islow(const int *coef /* dequantised, natural order */, uint8_t *out, 
         const int *in = coef + c;
         long *w = ws + c;
         if (!in[8] && !in[16] && !in[24] && !in[32] && !in[40] && !in[48] && !in[56]) {
-            long dc = (long)in[0] << P1;
+            long dc = (long)in[0] * (1L << P1); // (a left shift of a negative value is undefined before C++20)
             for (int r = 0; r < 8; ++r) w[8 * r] = dc;
             continue;
         }
@@ -118,7 +118,7 @@ void idct_islow(const int *coef /* dequantised, natural order */, uint8_t *out, 
         long z1 = (z2 + z3) * F_0_541;
         long t2 = z1 + z3 * (-F_1_847), t3 = z1 + z2 * F_0_765;
         z2 = in[0]; z3 = in[32];
-        long t0 = (z2 + z3) << CB, t1 = (z2 - z3) << CB;
+        long t0 = (z2 + z3) * (1L << CB), t1 = (z2 - z3) * (1L << CB);
         long t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
         t0 = in[56]; t1 = in[40]; t2 = in[24]; t3 = in[8];
         z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2;
@@ -138,7 +138,7 @@ void idct_islow(const int *coef /* dequantised, natural order */, uint8_t *out, 
         long z2 = w[2], z3 = w[6];
         long z1 = (z2 + z3) * F_0_541;
         long t2 = z1 + z3 * (-F_1_847), t3 = z1 + z2 * F_0_765;
-        long t0 = (w[0] + w[4]) << CB, t1 = (w[0] - w[4]) << CB;
+        long t0 = (w[0] + w[4]) * (1L << CB), t1 = (w[0] - w[4]) * (1L << CB);
         long t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
         t0 = w[7]; t1 = w[5]; t2 = w[3]; t3 = w[1];
         z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2;
