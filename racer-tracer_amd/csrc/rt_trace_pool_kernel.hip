@@ -83,7 +83,8 @@ __device__ __forceinline__ int lane_rank(uint64_t mask) { // set bits of `mask` 
 }
 
 // Per-wave scratch in LDS.  HAS_TIME: the scene has MovingSpheres (PRIMS_ANY variants).
-template <bool HAS_TIME> struct WaveLds {
+// NBUF: batches of camera samples kept (2, or 1 for the BVH variants, whose node array wants the LDS).
+template <bool HAS_TIME, int NBUF> struct WaveLds {
     // per pixel of the item's tile: upper_left_corner + u * horizontal with the pixel's ONE
     // horizontal jitter u = (px + ju) / (W - 1) (cpu.rs:35-36, camera.rs:331)
     double base[64][3];
@@ -91,10 +92,10 @@ template <bool HAS_TIME> struct WaveLds {
     uint4 req[64];      // cooperative sampler requests: {pixel, sample, segment, next candidate}
     int pix_of[64];     // pool slot -> lane-order pixel index, for tiles cut by the image edge
     // Camera samples of the pool entries, drawn 64 entries at a time by the WHOLE wave
-    // (prepare_batch below): entry w sits in slot w & 63 of buffer (w >> 6) & 1.
-    double v[2][64];        // (py + jv) / (H - 1)                      cpu.rs:39-40
-    double lens[2][64][2];  // random_in_unit_disk of the entry        camera.rs:327
-    double time[HAS_TIME ? 2 : 1][HAS_TIME ? 64 : 1]; // ray time      camera.rs:335
+    // (prepare_batch below): entry w sits in slot w & 63 of buffer (w >> 6) & (NBUF - 1).
+    double v[NBUF][64];        // (py + jv) / (H - 1)                      cpu.rs:39-40
+    double lens[NBUF][64][2];  // random_in_unit_disk of the entry        camera.rs:327
+    double time[HAS_TIME ? NBUF : 1][HAS_TIME ? 64 : 1]; // ray time      camera.rs:335
 };
 
 // vec3.rs:424-430 for every lane with `need`, evaluated by the whole wave.
@@ -182,7 +183,11 @@ __device__ __forceinline__ void coop_random_in_unit_disk(bool need, uint32_t pix
 // (instantiated for PRIMS_ANY only; chosen for scenes with many primitives).
 template <int PRIMS, bool TEXTURED, bool SPECULAR, bool BVH>
 __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : ((BVH || PRIMS == PRIMS_ANY) ? 4 : (SPECULAR ? RT_OCC_SPEC : 5))) void k_trace_pool_f64(const TraceArgs A) {
-    __shared__ WaveLds<PRIMS == PRIMS_ANY> lds_all[4];
+    // Two batches of camera samples stay ahead of the hand-out, so that it may straddle a batch
+    // boundary; the BVH variants keep one (their node array wants the LDS: three resident blocks
+    // instead of two on the `random` scene) and a hand-out stops at the end of its batch.
+    constexpr int NBUF = BVH ? 1 : 2;
+    __shared__ WaveLds<PRIMS == PRIMS_ANY, NBUF> lds_all[4];
     // The gradients of the first Perlin table (6 KB) are staged in LDS once per block when the
     // permutation tables are the identity (always, in the reference: noise.rs:121-130): the 56
     // random gradient fetches of a marble lookup then hit LDS instead of the vector memory
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : ((BVH || PRIMS == PRIM
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
-    WaveLds<PRIMS == PRIMS_ANY> &L = lds_all[threadIdx.x >> 6];
+    WaveLds<PRIMS == PRIMS_ANY, NBUF> &L = lds_all[threadIdx.x >> 6];
     unsigned int n_segments = 0;
 
     RT_REGION_DECL
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : ((BVH || PRIMS == PRIM
             uint32_t pixel_b = 0, sample_b = 0;
             if (in_pool) entry_of(w, pix_b, py_b, pixel_b, sample_b);
             const u4 bc = philox4x32_10(pixel_b, sample_b, RT_RNG_CAMERA, 0u, A.seed_lo, A.seed_hi);
-            const int buf = (int)(b & 1u);
+            const int buf = (int)(b & (uint32_t)(NBUF - 1));
             L.v[buf][lane] = ((double)py_b + u53(bc.a, bc.b)) * K->inv_height_m1; // cpu.rs:39-40
             // camera.rs:335: the ray's time, second double of the same block (MovingSphere reads it)
             if (PRIMS == PRIMS_ANY) L.time[buf][lane] = K->cam.time_a + (K->cam.time_b - K->cam.time_a) * u53(bc.c, bc.d);
@@ -326,18 +331,20 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : ((BVH || PRIMS == PRIM
 
         for (;;) {
             // ---- camera samples for the entries about to leave the pool (whole wave, see above)
-            while (batches_done < n_batches && batches_done <= (next >> 6) + 1u) prepare_batch(batches_done++);
+            while (batches_done < n_batches && batches_done <= (next >> 6) + (uint32_t)(NBUF - 1)) prepare_batch(batches_done++);
             RT_REGION(1); // batches
             // ---- hand pool entries to the lanes without a path (ballot + prefix count)
             if (next < total) {
                 const uint64_t idle = __ballot(!alive);
                 const uint32_t w = next + (uint32_t)lane_rank(idle);
-                next += (uint32_t)__popcll(idle);
-                if (!alive && w < total) { // cpu.rs:39-40 + camera.rs:326-337
+                // entries whose camera samples are in LDS: all of them with two buffers, the current batch with one
+                const uint32_t ready = NBUF == 2 ? total : min(total, batches_done << 6);
+                next = min(next + (uint32_t)__popcll(idle), ready);
+                if (!alive && w < ready) { // cpu.rs:39-40 + camera.rs:326-337
                     int py;
                     entry_of(w, pix, py, rng.pixel, rng.sample);
                     const RT_CONSTANT TraceArgs *K = kernargs_here();
-                    const int buf = (int)((w >> 6) & 1u), slot = (int)(w & 63u);
+                    const int buf = (int)((w >> 6) & (uint32_t)(NBUF - 1)), slot = (int)(w & 63u);
                     const double v = L.v[buf][slot];
                     const d3 co = ld3(K->cam.origin);
                     o = co;
