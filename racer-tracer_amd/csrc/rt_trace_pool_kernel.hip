@@ -4,7 +4,7 @@
 //
 // Replaces CpuRenderer::raytrace's pixel x sample loop
 // (racer-tracer/src/renderer/cpu.rs:26-71) and the recursive ray_color
-// (renderer.rs:41-90).  Three ideas, all measured against the v1 kernel
+// (renderer.rs:41-90).  The ideas, all measured against the v1 kernel
 // (rt_trace_kernel.hip) on cornell_box 1080p:
 //
 // 1. PERSISTENT WAVES + ITEM QUEUE.  The grid is sized to what is resident
@@ -32,6 +32,18 @@
 //    accepted candidate in stream order.  ~3 rounds instead of ~6.4, identical
 //    values (the accepted candidate is exactly the one the sequential loop
 //    would have stopped at).
+//
+// 4. REGENERATION BATCHES.  Pool entries leave in index order, so the camera samples
+//    (vertical jitter, ray time, lens disk) of 64 consecutive entries are drawn by the
+//    whole wave into LDS ahead of the hand-out instead of by the ~16 lanes that start a
+//    path in a given iteration.
+//
+// 5. UNIFORMS ARE RE-READ WHERE THEY ARE USED (kernargs_here): camera and background would
+//    otherwise sit in SGPRs across the path loop and be spilled to VGPR lanes.
+//
+// The launch is VALU-throughput bound (DESIGN.md 4.2 has the counters, the per-region
+// cycle profile of the -DRT_PROFILE_REGIONS build, and the variants that were measured and
+// dropped).
 #include <cstddef>
 #include <type_traits>
 #include "rt_trace_common.h"
