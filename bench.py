@@ -150,9 +150,10 @@ def main():
     p.strip_rows, p.strip_count, p.strip_index = STRIP_ROWS, world, rank
 
     scene = rt.Scene(session, device=local)
-    frame = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
     strips = importlib.import_module("racer-tracer_amd.strips")
     gatherer = strips.StripGather(H, W, STRIP_ROWS, world, rank, "cuda", dist)
+    # for N > 1 the frame lives in the gather's staging buffer: no copies besides the strips
+    frame = gatherer.frame() if world > 1 else torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream()
     kernel_ms, segments = [], []
 

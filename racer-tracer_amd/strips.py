@@ -19,12 +19,23 @@ class StripGather:
         self.world, self.rank, self.dist = world, rank, dist
         self.n_strips = (height + strip_rows - 1) // strip_rows
         self.per_rank = (self.n_strips + world - 1) // world  # padded so every rank sends the same size
-        self.pad_rows = self.n_strips * strip_rows
+        self.pad_rows = self.per_rank * world * strip_rows    # a whole number of strips for every rank
+        self.padded = None
         if world > 1:
             kw = dict(dtype=torch.float64, device=device)
+            # strip j = slot (j // world, j % world): one strided view per rank, one permute for all of them
             self.padded = torch.zeros((self.pad_rows, width, 3), **kw)
+            self.by_rank = self.padded.view(self.per_rank, world, strip_rows, width, 3)
             self.send = torch.zeros((self.per_rank, strip_rows, width, 3), **kw)
-            self.recv = [torch.zeros_like(self.send) for _ in range(world)] if rank == 0 else None
+            self.recv = torch.zeros((world, self.per_rank, strip_rows, width, 3), **kw) if rank == 0 else None
+
+    def frame(self):
+        """An [H, W, 3] frame to render into whose storage IS the gather's staging buffer, so
+        gather() moves nothing but the strips themselves.  (Any other [H, W, 3] tensor works
+        too, at the price of one copy in and one out.)"""
+        if self.padded is None:
+            raise RuntimeError("StripGather.frame() is only meaningful for world > 1")
+        return self.padded[: self.h]
 
     def owned(self, rank=None):
         """Strip indices owned by `rank` (default: this rank)."""
@@ -37,13 +48,15 @@ class StripGather:
 
     def gather(self, frame):
         """frame: [H, W, 3] float64 holding this rank's rows.  After the call
-        rank 0's frame holds every row.  No-op for world == 1."""
+        rank 0's frame holds every row.  No-op for world == 1.
+        Per step: one strided copy into the send buffer, ONE collective, and on rank 0 one
+        permuting copy back into the frame."""
         if self.world == 1:
             return frame
-        self.padded[: self.h].copy_(frame)
-        strips = self.padded.view(self.n_strips, self.rows, self.w, 3)
-        mine = strips[self.rank :: self.world]
-        self.send[: mine.shape[0]].copy_(mine)
+        own_storage = frame.data_ptr() == self.padded.data_ptr()
+        if not own_storage:
+            self.padded[: self.h].copy_(frame)
+        self.send.copy_(self.by_rank[:, self.rank])
         if self.send.is_cuda and self.dist.get_backend() == "gloo":
             # functional rehearsal of the N > 1 path on one GPU (several ranks share the
             # card, RCCL cannot): stage the collective through host memory
@@ -54,10 +67,9 @@ class StripGather:
                 for r in range(self.world):
                     self.recv[r].copy_(recv[r])
         else:
-            self.dist.gather(self.send, self.recv, dst=0)
+            self.dist.gather(self.send, [self.recv[r] for r in range(self.world)] if self.rank == 0 else None, dst=0)
         if self.rank == 0:
-            for r in range(self.world):
-                k = len(self.owned(r))
-                strips[r :: self.world] = self.recv[r][:k]
-            frame.copy_(self.padded[: self.h])
+            self.by_rank.copy_(self.recv.permute(1, 0, 2, 3, 4))
+            if not own_storage:
+                frame.copy_(self.padded[: self.h])
         return frame

@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, w, h, spp, rows, out_path):
+def _worker(rank, world, port, w, h, spp, rows, in_place, out_path):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
@@ -36,8 +36,12 @@ def _worker(rank, world, port, w, h, spp, rows, out_path):
         camera = S.camera_for(cam, w, h)
         params = S.abi.render_params(w, h, spp, strip_rows=rows, strip_count=world, strip_index=rank)
         part, _ = orc.render(bundle.desc, camera, params, n_threads=2)
-        frame = torch.from_numpy(part.copy())
         g = strips.StripGather(h, w, rows, world, rank, "cpu", dist)
+        if in_place:   # bench.py's way: the frame is the gather's own staging buffer
+            frame = g.frame()
+            frame.copy_(torch.from_numpy(part))
+        else:
+            frame = torch.from_numpy(part.copy())
         assert list(g.owned()) == list(range(rank, g.n_strips, world))
         assert bool((frame[~g.owned_row_mask()] == 0).all())
         g.gather(frame)
@@ -48,12 +52,12 @@ def _worker(rank, world, port, w, h, spp, rows, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,h,rows", [(2, 45, 8), (2, 40, 4), (3, 50, 8)])
-def test_two_rank_gather_equals_single_rank_frame(tmp_path, orc, world, h, rows):
+@pytest.mark.parametrize("world,h,rows,in_place", [(2, 45, 8, True), (2, 40, 4, False), (3, 50, 8, True), (3, 22, 8, False)])
+def test_two_rank_gather_equals_single_rank_frame(tmp_path, orc, world, h, rows, in_place):
     import scenes_py as S
     w, spp = 48, 3
     out = str(tmp_path / "frame.npy")
-    mp.spawn(_worker, args=(world, _free_port(), w, h, spp, rows, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), w, h, spp, rows, in_place, out), nprocs=world, join=True)
     got = np.load(out)
     bundle, cam, _ = S.three_balls()
     full, _ = orc.render(bundle.desc, S.camera_for(cam, w, h), S.abi.render_params(w, h, spp))
