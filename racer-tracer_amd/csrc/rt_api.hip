@@ -67,7 +67,6 @@ template <class T> struct DevBuf {
 struct RtScene {
     int device = 0;
     DevBuf<rtdev::Prim> prims;
-    DevBuf<rtdev::Material> materials;
     DevBuf<rtdev::Texture> textures;
     DevBuf<rtdev::Image> images;
     DevBuf<rtdev::Perlin> perlins;
@@ -199,7 +198,6 @@ int check_params(const RtCamera *camera, const RtRenderParams *p) {
 void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtdev::TraceArgs &a) {
     memset(&a, 0, sizeof a);
     a.prims = s->prims.ptr;
-    a.materials = s->materials.ptr;
     a.textures = s->textures.ptr;
     a.images = s->images.ptr;
     a.perlins = s->perlins.ptr;
@@ -443,7 +441,6 @@ void rt_scene_destroy(RtScene *s) {
     for (uint8_t *p : s->image_pixels)
         if (p) (void)hipFree(p);
     s->prims.release();
-    s->materials.release();
     s->textures.release();
     s->images.release();
     s->perlins.release();
@@ -534,7 +531,7 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
             for (int k = 0; k < 3; ++k) q.color[k] = t.color[k];
         }
     }
-    for (rtdev::Prim &q : prims) q.mat = materials[(size_t)q.material];
+    for (rtdev::Prim &q : prims) q.mat = materials[(size_t)q.material]; // the only device copy of a material
     std::vector<rtdev::Image> images((size_t)d->n_images);
     s->image_pixels.assign((size_t)d->n_images, nullptr);
     for (int i = 0; i < d->n_images; ++i) {
@@ -581,7 +578,6 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     }
     if ((rc = upload(s->prims, prims)) != RT_OK) return rc;
     if ((rc = upload(s->textures, textures)) != RT_OK) return rc;
-    if ((rc = upload(s->materials, materials)) != RT_OK) return rc;
     if ((rc = upload(s->images, images)) != RT_OK) return rc;
     if ((rc = upload(s->perlins, perlins)) != RT_OK) return rc;
     s->n_prims = d->n_primitives;

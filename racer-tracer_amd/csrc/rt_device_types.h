@@ -83,7 +83,6 @@ struct Background {
 // Kernel argument block (passed by value -> kernarg segment, scalar loads).
 struct TraceArgs {
     const Prim *prims;
-    const Material *materials;
     const Texture *textures;
     const Image *images;
     const Perlin *perlins;
