@@ -1,6 +1,6 @@
 /* rt_rng.h — the random-number CONTRACT shared by the device path and the
  * CPU oracle.  This header holds the addressing scheme only (constants and
- * prose); each side carries its own implementation of Philox4x32-10 so the
+ * prose); each side carries its own implementation of Philox4x32 so the
  * oracle stays an independent check.
  *
  * Why a contract at all: the reference draws everything from
@@ -9,7 +9,7 @@
  * draw ORDER and distribution but address every draw by
  * what it is for instead of by "the n-th call on this thread".  A draw is
  *
- *     out  = philox4x32_10(ctr = {pixel, sample, (segment << 8) | purpose, block},
+ *     out  = philox4x32_R(ctr = {pixel, sample, (segment << 8) | purpose, block},     R = RT_PHILOX_ROUNDS
  *                          key = {seed & 0xffffffff, seed >> 32})
  *     d0   = u53(out[0], out[1])        d1 = u53(out[2], out[3])
  *     u53(hi, lo) = (((uint64)hi << 32 | lo) >> 11) * 2^-53      in [0,1)
@@ -55,7 +55,14 @@
                             /* pixel = n for the loader's n-th random_double(), sample =      */
                             /* RT_RNG_SAMPLE_TABLE, segment 0, block 0: d0                     */
 
-/* Philox4x32-10 constants (Salmon et al., SC'11). */
+/* Philox4x32 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3",
+ * SC'11) with SEVEN rounds: the paper's Crush-resistant member of the family (Philox4x32-7
+ * passes TestU01 BigCrush; the usual -10 adds three rounds of safety margin that a Monte
+ * Carlo integrator has no use for, and the generator is ~1/4 of this path's instructions).
+ * Both round counts are pinned by Random123's published known-answer vectors
+ * (tests/test_oracle_reference_vectors.py).  The reference itself draws from rand 0.8's
+ * ThreadRng (ChaCha12), a different family altogether: only the distribution is matched. */
+#define RT_PHILOX_ROUNDS 7
 #define RT_PHILOX_M0 0xD2511F53u
 #define RT_PHILOX_M1 0xCD9E8D57u
 #define RT_PHILOX_W0 0x9E3779B9u

@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 /* ---- RNG (include/rt_rng.h contract) ---- */
-void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]);
 /* d0 (which=0) or d1 (which=1) of the addressed block */
 double orc_rng_double(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t segment,
                       uint32_t purpose, uint32_t block, int which);

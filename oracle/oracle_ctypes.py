@@ -37,7 +37,7 @@ _P = C.POINTER
 _D = C.c_double
 _PD = _P(_D)
 _PROTOS = {
-    "orc_philox4x32_10": (None, [_P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint32)]),
+    "orc_philox4x32": (None, [_P(C.c_uint32), _P(C.c_uint32), C.c_int, _P(C.c_uint32)]),
     "orc_rng_double": (_D, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                             C.c_uint32, C.c_int]),
     "orc_vec3_add": (None, [_PD, _PD, _PD]),

@@ -1,4 +1,4 @@
-/* philox.c — Philox4x32-10 and the draw addressing of include/rt_rng.h.
+/* philox.c — Philox4x32-R and the draw addressing of include/rt_rng.h (R = RT_PHILOX_ROUNDS).
  *
  * TEST INFRASTRUCTURE (see oracle.h).  The algorithm is the published one
  * (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2,
@@ -16,10 +16,10 @@ static inline void mulhilo(uint32_t a, uint32_t b, uint32_t *hi, uint32_t *lo) {
     *lo = (uint32_t)p;
 }
 
-void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]) {
     uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
     uint32_t k0 = key[0], k1 = key[1];
-    for (int round = 0; round < 10; ++round) {
+    for (int round = 0; round < rounds; ++round) {
         uint32_t hi0, lo0, hi1, lo1;
         mulhilo(RT_PHILOX_M0, c0, &hi0, &lo0);
         mulhilo(RT_PHILOX_M1, c2, &hi1, &lo1);
@@ -44,6 +44,6 @@ double orc_rng_double(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t s
     uint32_t ctr[4] = { pixel, sample, (segment << 8) | purpose, block };
     uint32_t key[2] = { (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32) };
     uint32_t out[4];
-    orc_philox4x32_10(ctr, key, out);
+    orc_philox4x32(ctr, key, RT_PHILOX_ROUNDS, out);
     return which ? u53(out[2], out[3]) : u53(out[0], out[1]);
 }

@@ -96,10 +96,10 @@ __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
     return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
 }
 
-__device__ __forceinline__ u4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+__device__ __forceinline__ u4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                             uint32_t k0, uint32_t k1) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < RT_PHILOX_ROUNDS; ++r) {
         uint64_t p0 = (uint64_t)RT_PHILOX_M0 * c0;
         uint64_t p1 = (uint64_t)RT_PHILOX_M1 * c2;
         uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
@@ -133,7 +133,7 @@ __device__ __forceinline__ double sym53(uint32_t hi, uint32_t lo) {
 struct PathRng {
     uint32_t pixel, sample, k0, k1;
     __device__ __forceinline__ u4 block(uint32_t segment, uint32_t purpose, uint32_t blk) const {
-        return philox4x32_10(pixel, sample, (segment << 8) | purpose, blk, k0, k1);
+        return philox4x32(pixel, sample, (segment << 8) | purpose, blk, k0, k1);
     }
 };
 

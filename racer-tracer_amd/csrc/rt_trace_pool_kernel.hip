@@ -131,8 +131,8 @@ __device__ __forceinline__ bool coop_random_in_unit_sphere(bool need, uint32_t p
         const bool serving = j < n;
         const uint4 r = req[serving ? j : 0];
         const uint32_t i = r.w + (uint32_t)c;  // candidate index: blocks 2i and 2i+1 (rt_rng.h)
-        const u4 b0 = philox4x32_10(r.x, r.y, (r.z << 8) | RT_RNG_SCATTER, 2u * i, k0, k1);
-        const u4 b1 = philox4x32_10(r.x, r.y, (r.z << 8) | RT_RNG_SCATTER, 2u * i + 1u, k0, k1);
+        const u4 b0 = philox4x32(r.x, r.y, (r.z << 8) | RT_RNG_SCATTER, 2u * i, k0, k1);
+        const u4 b1 = philox4x32(r.x, r.y, (r.z << 8) | RT_RNG_SCATTER, 2u * i + 1u, k0, k1);
         const d3 p = mk(sym53(b0.a, b0.b), sym53(b0.c, b0.d), sym53(b1.a, b1.b));
         const uint64_t accepted = __ballot(serving && len2(p) < 1.0);
         // first accepted candidate of my own request, in stream order
@@ -171,7 +171,7 @@ __device__ __forceinline__ void coop_random_in_unit_disk(bool need, uint32_t pix
         const int c = lane & ((1 << lg) - 1);
         const bool serving = j < n;
         const uint4 r = req[serving ? j : 0];
-        const u4 b = philox4x32_10(r.x, r.y, RT_RNG_LENS, r.w + (uint32_t)c, k0, k1);
+        const u4 b = philox4x32(r.x, r.y, RT_RNG_LENS, r.w + (uint32_t)c, k0, k1);
         const double x = sym53(b.a, b.b), y = sym53(b.c, b.d);
         const uint64_t accepted = __ballot(serving && x * x + y * y < 1.0);
         const int first = need ? (rank << lg) : 0;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : ((BVH || PRIMS == PRIM
             int pix_b = 0, py_b = 0;
             uint32_t pixel_b = 0, sample_b = 0;
             if (in_pool) entry_of(w, pix_b, py_b, pixel_b, sample_b);
-            const u4 bc = philox4x32_10(pixel_b, sample_b, RT_RNG_CAMERA, 0u, A.seed_lo, A.seed_hi);
+            const u4 bc = philox4x32(pixel_b, sample_b, RT_RNG_CAMERA, 0u, A.seed_lo, A.seed_hi);
             const int buf = (int)(b & (uint32_t)(NBUF - 1));
             L.v[buf][lane] = ((double)py_b + u53(bc.a, bc.b)) * K->inv_height_m1; // cpu.rs:39-40
             // camera.rs:335: the ray's time, second double of the same block (MovingSphere reads it)

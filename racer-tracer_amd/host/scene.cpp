@@ -11,12 +11,12 @@
 namespace rthost {
 
 // ------------------------------------------------------------ host-side RNG
-// Philox4x32-10 (include/rt_rng.h); used only to fill the Perlin gradient
+// Philox4x32-R, R = RT_PHILOX_ROUNDS (include/rt_rng.h); used only to fill the Perlin gradient
 // table, which the reference fills from thread_rng (noise.rs:45-47).
-static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+static void philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
     uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
     uint32_t k0 = key[0], k1 = key[1];
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < RT_PHILOX_ROUNDS; ++r) {
         uint64_t p0 = (uint64_t)RT_PHILOX_M0 * c[0], p1 = (uint64_t)RT_PHILOX_M1 * c[2];
         uint32_t n[4] = {(uint32_t)(p1 >> 32) ^ c[1] ^ k0, (uint32_t)p1, (uint32_t)(p0 >> 32) ^ c[3] ^ k1, (uint32_t)p0};
         memcpy(c, n, sizeof c);
@@ -34,8 +34,8 @@ Perlin::Perlin(uint64_t seed, uint32_t perlin_index) {
     for (uint32_t i = 0; i < 256; ++i) { // noise.rs:45-47: Vec3::random_range(-1, 1).unit_vector()
         uint32_t c0[4] = {i, RT_RNG_SAMPLE_TABLE, (perlin_index << 8) | RT_RNG_PERLIN, 0}, o0[4], o1[4];
         uint32_t c1[4] = {i, RT_RNG_SAMPLE_TABLE, (perlin_index << 8) | RT_RNG_PERLIN, 1};
-        philox4x32_10(c0, key, o0);
-        philox4x32_10(c1, key, o1);
+        philox4x32(c0, key, o0);
+        philox4x32(c1, key, o1);
         Vec3 v(-1.0 + 2.0 * u53(o0[0], o0[1]), -1.0 + 2.0 * u53(o0[2], o0[3]), -1.0 + 2.0 * u53(o1[0], o1[1]));
         Vec3 g = v.unit_vector();
         for (int k = 0; k < 3; ++k) table.ranvec[i][k] = g[k];
@@ -495,7 +495,7 @@ SceneLoadData RandomLoader::load() const { // scene/random.rs:25-96
     uint32_t n = 0;
     auto random_double = [&]() {
         uint32_t ctr[4] = {n++, RT_RNG_SAMPLE_TABLE, RT_RNG_SCENE, 0}, out[4];
-        philox4x32_10(ctr, key, out);
+        philox4x32(ctr, key, out);
         return u53(out[0], out[1]);
     };
     auto random_range = [&](double a, double b) { return a + (b - a) * random_double(); };

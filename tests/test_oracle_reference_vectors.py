@@ -2,7 +2,7 @@
 
 1. the reference's own unit tests (racer-tracer/src/vec3.rs:446-503) replayed
    on the oracle's Vec3 operators;
-2. the published Philox4x32-10 known-answer vectors (Random123 kat_vectors),
+2. the published Philox4x32 known-answer vectors for 7 and 10 rounds (Random123 kat_vectors),
    since the RNG replaces the un-vendored, unseedable `rand 0.8.5`;
 3. pixels of the reference's own output images (assets/*.png, committed as
    values in tests/golden/reference_assets.json): sky pixels must match
@@ -54,28 +54,42 @@ def test_reference_vec3_div(orc):  # vec3.rs:494-502
     assert v3(orc, "orc_vec3_div", (1.0, -2.0, 3.0), 2.0) == [0.5, -1.0, 1.5]
 
 
-# ---- 2. Philox4x32-10 known answers -----------------------------------------
+# ---- 2. Philox4x32 known answers ---------------------------------------------
+# Random123's kat_vectors lines "philox4x32 7 ..." and "philox4x32 10 ...": counter, key, output.
+# The contract (include/rt_rng.h) runs 7 rounds; the 10-round vectors pin the same round function.
 PHILOX_KATS = [
-    ((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
-    ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
-    ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+    (7, (0, 0, 0, 0), (0, 0), (0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48)),
+    (7, (0xffffffff,) * 4, (0xffffffff,) * 2, (0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662)),
+    (7, (0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+     (0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a)),
+    (10, (0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+    (10, (0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+    (10, (0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
      (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
 ]
+CONTRACT_ROUNDS = 7   # RT_PHILOX_ROUNDS
 
 
-@pytest.mark.parametrize("ctr,key,expect", PHILOX_KATS)
-def test_philox_known_answers(orc, ctr, key, expect):
+@pytest.mark.parametrize("rounds,ctr,key,expect", PHILOX_KATS)
+def test_philox_known_answers(orc, rounds, ctr, key, expect):
     out = (C.c_uint32 * 4)()
-    orc.lib().orc_philox4x32_10((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
+    orc.lib().orc_philox4x32((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), rounds, out)
     assert tuple(out) == expect
+
+
+def test_contract_rounds_match_the_header():
+    import os
+    import re
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "rt_rng.h")).read()
+    assert int(re.search(r"#define RT_PHILOX_ROUNDS (\d+)", text).group(1)) == CONTRACT_ROUNDS
 
 
 def test_rng_double_is_53_bit_of_addressed_block(orc):
     """include/rt_rng.h: d0 = u53(out[0], out[1]), d1 = u53(out[2], out[3])."""
     seed, pixel, sample, seg, purpose, block = 0x0123456789ABCDEF, 77, 5, 3, 3, 9
     out = (C.c_uint32 * 4)()
-    orc.lib().orc_philox4x32_10((C.c_uint32 * 4)(pixel, sample, (seg << 8) | purpose, block),
-                                (C.c_uint32 * 2)(seed & 0xffffffff, seed >> 32), out)
+    orc.lib().orc_philox4x32((C.c_uint32 * 4)(pixel, sample, (seg << 8) | purpose, block),
+                             (C.c_uint32 * 2)(seed & 0xffffffff, seed >> 32), CONTRACT_ROUNDS, out)
     for which, (hi, lo) in enumerate(((out[0], out[1]), (out[2], out[3]))):
         want = float(((hi << 32 | lo) >> 11)) * 2.0 ** -53
         got = orc.lib().orc_rng_double(seed, pixel, sample, seg, purpose, block, which)
@@ -87,6 +101,55 @@ def test_rng_uniformity(orc):
     assert abs(xs.mean() - 0.5) < 0.01 and abs(xs.var() - 1 / 12) < 0.005
     hist, _ = np.histogram(xs, bins=10, range=(0, 1))
     assert hist.min() > 1800 and hist.max() < 2200
+
+
+def _philox_np(ctr, key, rounds):
+    """Vectorised numpy Philox4x32 (a third implementation, only for the statistics below)."""
+    M0, M1, W0, W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), 0x9E3779B9, 0xBB67AE85
+    c = [np.asarray(x, dtype=np.uint64) & np.uint64(0xffffffff) for x in ctr]
+    k0, k1 = int(key[0]), int(key[1])
+    mask = np.uint64(0xffffffff)
+    for _ in range(rounds):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [(p1 >> np.uint64(32)) ^ c[1] ^ np.uint64(k0), p1 & mask, (p0 >> np.uint64(32)) ^ c[3] ^ np.uint64(k1), p0 & mask]
+        k0, k1 = (k0 + W0) & 0xffffffff, (k1 + W1) & 0xffffffff
+    return c
+
+
+def test_numpy_philox_agrees_with_the_oracle(orc):
+    out = (C.c_uint32 * 4)()
+    orc.lib().orc_philox4x32((C.c_uint32 * 4)(123, 45, 678, 9), (C.c_uint32 * 2)(1, 0), CONTRACT_ROUNDS, out)
+    got = _philox_np((np.array([123]), np.array([45]), np.array([678]), np.array([9])), (1, 0), CONTRACT_ROUNDS)
+    assert [int(x[0]) for x in got] == list(out)
+
+
+@pytest.mark.parametrize("word", [0, 1, 2, 3])
+def test_contract_rounds_decorrelate_adjacent_addresses(word):
+    """The draws of this path differ in ONE counter word by small steps (next pixel, next
+    sample, next segment/purpose, next block).  With the contract's round count the outputs of
+    such neighbours must look independent: flipping a low counter bit flips half of the 128
+    output bits (avalanche), and the doubles of consecutive addresses are uncorrelated and
+    uniform in 2-D."""
+    n = 1 << 16
+    base = [np.full(n, 1234567, dtype=np.uint64), np.full(n, 89, dtype=np.uint64),
+            np.full(n, (3 << 8) | 3, dtype=np.uint64), np.full(n, 0, dtype=np.uint64)]
+    ctr = [b.copy() for b in base]
+    ctr[word] = ctr[word] + np.arange(n, dtype=np.uint64)
+    out = _philox_np(ctr, (1, 0), CONTRACT_ROUNDS)
+    # avalanche: neighbour (+1 in that word) differs in ~64 of 128 bits
+    flipped = sum(np.unpackbits(((a[1:] ^ a[:-1]) & np.uint64(0xffffffff)).astype(">u4").view(np.uint8)).sum() for a in out)
+    per_pair = flipped / (n - 1)
+    assert abs(per_pair - 64.0) < 0.2                         # sigma of the mean ~ 0.022
+    x = ((out[0] << np.uint64(32) | out[1]) >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+    y = ((out[2] << np.uint64(32) | out[3]) >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+    for u in (x, y):
+        assert abs(u.mean() - 0.5) < 0.005 and abs(u.var() - 1.0 / 12.0) < 0.002
+        assert abs(np.corrcoef(u[:-1], u[1:])[0, 1]) < 0.02   # lag-1 over consecutive addresses
+    assert abs(np.corrcoef(x, y)[0, 1]) < 0.02
+    grid, _, _ = np.histogram2d(x[:-1], x[1:], bins=16, range=((0, 1), (0, 1)))
+    expect = (n - 1) / 256.0
+    chi2 = ((grid - expect) ** 2 / expect).sum()
+    assert chi2 < 255 + 6 * np.sqrt(2 * 255)                   # 255 dof, six sigma
 
 
 # ---- 3. the reference's own output images -----------------------------------
