@@ -827,9 +827,10 @@ int rt_scene_last_stats(RtScene *s, RtRenderStats *out) {
         static const char *names[10] = {"item setup", "batches", "hand-out + primary ray", "closest hit", "miss/hit/material",
                                         "sampler", "scatter + accumulate", "item end", "-", "-"};
         double total = 0;
-        for (int k = 0; k < 10; ++k) total += (double)c[1 + k];
+        for (int k = 0; k < 8; ++k) total += (double)c[1 + k];
         for (int k = 0; k < 8; ++k)
             fprintf(stderr, "region %-24s %6.2f %%  (%.3g wave-cycles)\n", names[k], 100.0 * (double)c[1 + k] / total, (double)c[1 + k]);
+        if (c[9]) fprintf(stderr, "noise lookups: %.3g wave-iterations with one, %.1f lanes each on average\n", (double)c[9], (double)c[10] / (double)c[9]);
         // 100 MHz wall clock: when did the first/last wave start and end (last launch of the call)
         fprintf(stderr, "waves: last start +%.3f ms, first end +%.3f ms, last end +%.3f ms after the first start\n",
                 (double)(c[12] - c[11]) * 1e-5, (double)(c[13] - c[11]) * 1e-5, (double)(c[14] - c[11]) * 1e-5);

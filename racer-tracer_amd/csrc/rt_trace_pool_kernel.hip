@@ -422,6 +422,15 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : ((BVH || PRIMS == PRIM
                         const Material &M = P.mat;
                         const Hit h = prim_hit_record<PRIMS, TEXTURED>(P, o, d, ray_time, best_t, best_aux, M.needs_uv != 0);
                         const int kind = M.kind;
+#ifdef RT_PROFILE_REGIONS
+                        { // how many lanes of an iteration look up a Noise texture together?
+                            const int n_noise = __popcll(__ballot(TEXTURED && M.tex_kind == RT_TEX_NOISE));
+                            if (n_noise > 0 && lane_rank(__ballot(1)) == 0) {
+                                rt_t_[8] += 1;
+                                rt_t_[9] += (unsigned long long)n_noise;
+                            }
+                        }
+#endif
                         if (kind == RT_MAT_DIFFUSE_LIGHT) { // diffuse_light.rs:25-37
                             contrib = T * texture_value<TEXTURED>(A, lds_perlin, M, h.u, h.v, h.point);
                             ended = true;
