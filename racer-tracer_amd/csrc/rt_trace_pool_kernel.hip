@@ -231,6 +231,18 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : ((BVH || PRIMS == PRIM
         lds_nodes = reinterpret_cast<const BvhNode *>(dyn_lds);
         __syncthreads();
     }
+    // The linear-loop variants stage the whole primitive table (192 B each, materials included)
+    // in dynamic LDS instead: the closest-hit loop keeps reading it through the scalar cache, but
+    // the per-lane fetch of the WINNING primitive for shading is then an LDS read, not a trip
+    // through the vector memory path in the middle of every iteration.
+    const Prim *lds_prims = nullptr;
+    if (!BVH) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(A.prims);
+        uint4 *dst = reinterpret_cast<uint4 *>(dyn_lds);
+        for (int i = threadIdx.x; i < A.n_prims * (int)(sizeof(Prim) / 16); i += 256) dst[i] = src[i];
+        lds_prims = reinterpret_cast<const Prim *>(dyn_lds);
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     WaveLds<PRIMS == PRIMS_ANY, NBUF> &L = lds_all[threadIdx.x >> 6];
     unsigned int n_segments = 0;
@@ -427,7 +439,7 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : ((BVH || PRIMS == PRIM
                         contrib = T * bgc;
                         ended = true;
                     } else {
-                        const Prim &P = A.prims[best];
+                        const Prim &P = BVH ? A.prims[best] : lds_prims[best];
                         const Material &M = P.mat;
                         const Hit h = prim_hit_record<PRIMS, TEXTURED>(P, o, d, ray_time, best_t, best_aux, M.needs_uv != 0);
                         const int kind = M.kind;
@@ -601,7 +613,7 @@ namespace {
 // linear closest-hit loop, plus PRIMS_ANY x TEXTURED x SPECULAR with the BVH.
 template <int PRIMS, bool TEXTURED, bool SPECULAR, bool BVH> struct PoolVariant {
     static void launch(const rtdev::TraceArgs &a, unsigned blocks, hipStream_t stream) {
-        const size_t dyn = BVH ? (size_t)a.bvh_lds_nodes * sizeof(rtdev::BvhNode) : 0;
+        const size_t dyn = BVH ? (size_t)a.bvh_lds_nodes * sizeof(rtdev::BvhNode) : (size_t)a.n_prims * sizeof(rtdev::Prim);
         hipLaunchKernelGGL((rtdev::k_trace_pool_f64<PRIMS, TEXTURED, SPECULAR, BVH>), dim3(blocks), dim3(256), dyn, stream, a);
     }
     static int blocks_per_cu(size_t dyn_lds) {
