@@ -596,7 +596,7 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     if (const char *k = getenv("RT_BVH_LDS")) s->bvh_nodes_in_lds = s->bvh_nodes_in_lds && atoi(k) != 0; // developer knob
     // dynamic LDS of the variant: the BVH node array, or the primitive table of the linear-loop variants
     const size_t dyn_lds = s->use_bvh ? (s->bvh_nodes_in_lds ? (size_t)s->n_bvh_nodes * sizeof(rtdev::BvhNode) : 0)
-                                      : (size_t)s->n_prims * sizeof(rtdev::Prim);
+                                      : (size_t)s->n_prims * sizeof(rtdev::Prim) + (s->textured ? (size_t)s->n_textures * sizeof(rtdev::Texture) : 0);
     s->pool_blocks_per_cu = rtdev_pool_blocks_per_cu(s->prims_class, s->textured, s->specular, s->use_bvh, dyn_lds);
     if (const char *k = getenv("RT_POOL_BLOCKS_PER_CU")) // developer knob for occupancy experiments
         if (atoi(k) > 0) s->pool_blocks_per_cu = atoi(k);

@@ -461,13 +461,14 @@ __device__ __forceinline__ int sin_sign(double x) {
 
 // Texture::value for everything that is not a plain SolidColor.
 // lds_perlin: LDS copy of A.perlins[0], or nullptr.
-__device__ __forceinline__ d3 texture_value_full(const TraceArgs &A, const Perlin *lds_perlin, int ti, double u, double v,
-                                                 d3 p) {
-    const Texture *T = &A.textures[ti];
+// `textures`: the texture table (A.textures, or the pooled kernel's LDS copy of it).
+__device__ __forceinline__ d3 texture_value_full(const TraceArgs &A, const Perlin *lds_perlin, const Texture *textures, int ti,
+                                                 double u, double v, d3 p) {
+    const Texture *T = &textures[ti];
     if (T->kind == RT_TEX_CHECKERED) { // checkered.rs:32-42
         // sines = sin(10x) * sin(10y) * sin(10z) < 0  <=>  an odd number of negative factors, none zero
         const int sines = sin_sign(p.x * 10.0) * sin_sign(p.y * 10.0) * sin_sign(p.z * 10.0);
-        T = &A.textures[sines < 0 ? T->tex_odd : T->tex_even];
+        T = &textures[sines < 0 ? T->tex_odd : T->tex_even];
     }
     const int kind = T->kind;
     if (kind == RT_TEX_IMAGE) { // texture/image.rs:28-51
@@ -496,10 +497,10 @@ __device__ __forceinline__ d3 texture_value_full(const TraceArgs &A, const Perli
 }
 
 template <bool TEXTURED>
-__device__ __forceinline__ d3 texture_value(const TraceArgs &A, const Perlin *lds_perlin, const Material &M, double u,
-                                            double v, d3 p) {
+__device__ __forceinline__ d3 texture_value(const TraceArgs &A, const Perlin *lds_perlin, const Texture *textures,
+                                            const Material &M, double u, double v, d3 p) {
     if (!TEXTURED || M.tex_kind == RT_TEX_SOLID_COLOR) return ld3(M.color); // solid_color.rs:24-28
-    return texture_value_full(A, lds_perlin, M.texture, u, v, p);
+    return texture_value_full(A, lds_perlin, textures, M.texture, u, v, p);
 }
 
 } // namespace rtdev

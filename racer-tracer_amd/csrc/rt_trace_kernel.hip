@@ -115,12 +115,12 @@ __global__ __launch_bounds__(256) void k_trace_f64(const TraceArgs A) {
                 const Material &M = P.mat;
                 Hit h = prim_hit_record<PRIMS, TEXTURED>(P, o, d, ray_time, best_t, best_aux, M.needs_uv != 0);
                 if (M.kind == RT_MAT_DIFFUSE_LIGHT) { // diffuse_light.rs:25-37
-                    contrib = T * texture_value<TEXTURED>(A, nullptr, M, h.u, h.v, h.point);
+                    contrib = T * texture_value<TEXTURED>(A, nullptr, A.textures, M, h.u, h.v, h.point);
                     ended = true;
                 } else if (M.kind == RT_MAT_LAMBERTIAN) { // lambertian.rs:26-38
                     d3 dir = h.normal + unit_fast(random_in_unit_sphere(rng, seg));
                     if (fabs(dir.x) < 1e-8 && fabs(dir.y) < 1e-8 && fabs(dir.z) < 1e-8) dir = h.normal;
-                    T = T * texture_value<TEXTURED>(A, nullptr, M, h.u, h.v, h.point);
+                    T = T * texture_value<TEXTURED>(A, nullptr, A.textures, M, h.u, h.v, h.point);
                     o = h.point;
                     d = dir;
                     ended = false;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_trace_f64(const TraceArgs A) {
                         contrib = mk(0.0, 0.0, 0.0);
                         ended = true;
                     } else {
-                        T = T * texture_value<TEXTURED>(A, nullptr, M, h.u, h.v, h.point);
+                        T = T * texture_value<TEXTURED>(A, nullptr, A.textures, M, h.u, h.v, h.point);
                         o = h.point;
                         d = dir;
                         ended = false;

@@ -243,6 +243,16 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : ((BVH || PRIMS == PRIM
         lds_prims = reinterpret_cast<const Prim *>(dyn_lds);
         __syncthreads();
     }
+    // ... and the texture table (64 B each) behind it: a Checkered lookup is a dependent chain
+    // texture -> sub-texture
+    const Texture *lds_textures = nullptr;
+    if (!BVH && TEXTURED) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(A.textures);
+        uint4 *dst = reinterpret_cast<uint4 *>(dyn_lds + (size_t)A.n_prims * sizeof(Prim));
+        for (int i = threadIdx.x; i < A.n_textures * (int)(sizeof(Texture) / 16); i += 256) dst[i] = src[i];
+        lds_textures = reinterpret_cast<const Texture *>(dyn_lds + (size_t)A.n_prims * sizeof(Prim));
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     WaveLds<PRIMS == PRIMS_ANY, NBUF> &L = lds_all[threadIdx.x >> 6];
     unsigned int n_segments = 0;
@@ -452,18 +462,25 @@ __global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : ((BVH || PRIMS == PRIM
                             }
                         }
 #endif
+                        // Texture::value once for every material that has one (light, Lambertian, Metal):
+                        // one copy of the texture code, shared by the lanes of all three
+                        d3 tex = mk(0.0, 0.0, 0.0);
+                        if (kind != RT_MAT_DIELECTRIC) {
+                            if (BVH) tex = texture_value<TEXTURED>(A, lds_perlin, A.textures, M, h.u, h.v, h.point);
+                            else tex = texture_value<TEXTURED>(A, lds_perlin, lds_textures, M, h.u, h.v, h.point);
+                        }
                         if (kind == RT_MAT_DIFFUSE_LIGHT) { // diffuse_light.rs:25-37
-                            contrib = T * texture_value<TEXTURED>(A, lds_perlin, M, h.u, h.v, h.point);
+                            contrib = T * tex;
                             ended = true;
                         } else if (kind == RT_MAT_LAMBERTIAN) { // lambertian.rs:26-38 (direction below)
-                            albedo = texture_value<TEXTURED>(A, lds_perlin, M, h.u, h.v, h.point);
+                            albedo = tex;
                             hit_point = h.point;
                             hit_normal = h.normal;
                             is_lambert = true;
                             waiting = true;
                             cand_base = 0;
                         } else if (SPECULAR && kind == RT_MAT_METAL) { // metal.rs:26-43 (fuzz below)
-                            albedo = texture_value<TEXTURED>(A, lds_perlin, M, h.u, h.v, h.point);
+                            albedo = tex;
                             hit_point = h.point;
                             hit_normal = h.normal;
                             fuzz = M.fuzz;
@@ -613,7 +630,8 @@ namespace {
 // linear closest-hit loop, plus PRIMS_ANY x TEXTURED x SPECULAR with the BVH.
 template <int PRIMS, bool TEXTURED, bool SPECULAR, bool BVH> struct PoolVariant {
     static void launch(const rtdev::TraceArgs &a, unsigned blocks, hipStream_t stream) {
-        const size_t dyn = BVH ? (size_t)a.bvh_lds_nodes * sizeof(rtdev::BvhNode) : (size_t)a.n_prims * sizeof(rtdev::Prim);
+        const size_t dyn = BVH ? (size_t)a.bvh_lds_nodes * sizeof(rtdev::BvhNode)
+                               : (size_t)a.n_prims * sizeof(rtdev::Prim) + (TEXTURED ? (size_t)a.n_textures * sizeof(rtdev::Texture) : 0);
         hipLaunchKernelGGL((rtdev::k_trace_pool_f64<PRIMS, TEXTURED, SPECULAR, BVH>), dim3(blocks), dim3(256), dyn, stream, a);
     }
     static int blocks_per_cu(size_t dyn_lds) {
