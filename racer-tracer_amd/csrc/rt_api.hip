@@ -566,6 +566,8 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     const int kBvhThreshold = 48;
     s->use_bvh = d->n_primitives > kBvhThreshold;
     if (const char *k = getenv("RT_BVH")) s->use_bvh = atoi(k) != 0 && d->n_primitives > 0; // developer knob
+    // (the linear-loop variants keep the whole primitive table in LDS: forcing them onto a scene of more than
+    // ~600 primitives exceeds a workgroup's LDS and the launch fails with RT_ERR_HIP)
     if (s->use_bvh) {
         rtdev::BvhBuild bvh = rtdev::build_bvh(d->primitives, d->n_primitives);
         if ((rc = upload(s->bvh_nodes, bvh.nodes)) != RT_OK) return rc;
