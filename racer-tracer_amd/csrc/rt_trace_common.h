@@ -170,17 +170,29 @@ __device__ __forceinline__ d3 rot_back(d3 a, double s, double c) { // rotate_y.r
 
 // One axis-aligned rect in its own frame; `axis` = constant axis.
 // xy_rect.rs:29-40 / xz_rect.rs / yz_rect.rs
+// EARLY_OUT: leave after the t-range test when no lane passes it.  That pays for free-standing
+// rects (cornell's walls: -4 % without it) and costs for the six sides of a box, where the
+// predicate form saves a wave twelve stops to test `exec` (cornell_box_boxes +6 %).
+template <bool EARLY_OUT>
 __device__ __forceinline__ bool rect_t(int axis, double a0, double a1, double b0, double b1, double k,
                                        d3 o, d3 d, d3 inv_d, double t_min, double t_max, double &t_out) {
     int ia = axis == 0 ? 1 : 0;
     int ib = axis == 2 ? 1 : 2;
-    double t = (k - comp(o, axis)) * comp(inv_d, axis); // xy_rect.rs:31 divides; inv_d = 1/d per ray
-    if (t < t_min || t > t_max) return false;
-    double a = comp(o, ia) + t * comp(d, ia);
-    double b = comp(o, ib) + t * comp(d, ib);
-    if (a < a0 || a > a1 || b < b0 || b > b1) return false;
+    const double t = (k - comp(o, axis)) * comp(inv_d, axis); // xy_rect.rs:31 divides; inv_d = 1/d per ray
+    if (EARLY_OUT) {
+        if (t < t_min || t > t_max) return false;
+        const double a = comp(o, ia) + t * comp(d, ia);
+        const double b = comp(o, ib) + t * comp(d, ib);
+        if (a < a0 || a > a1 || b < b0 || b > b1) return false;
+        t_out = t;
+        return true;
+    }
+    const double a = comp(o, ia) + t * comp(d, ia);
+    const double b = comp(o, ib) + t * comp(d, ib);
+    // the two early returns as one predicate (same comparisons, so NaNs fall the same way)
+    const bool miss = (t < t_min) | (t > t_max) | (a < a0) | (a > a1) | (b < b0) | (b > b1);
     t_out = t;
-    return true;
+    return !miss;
 }
 
 // box.rs:22-71 side s of a Boxx: axis and (a0,a1,b0,b1,k)
@@ -202,9 +214,9 @@ __device__ __forceinline__ bool prim_t(const Prim &P, d3 o, d3 d, d3 inv_d, doub
     aux = 0;
     if (PRIMS == PRIMS_RECTS) { // untransformed rects only: kind picks the axis
         int kind = P.kind;
-        if (kind == RT_PRIM_XY_RECT) return rect_t(2, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, t_min, t_max, t_out);
-        if (kind == RT_PRIM_XZ_RECT) return rect_t(1, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, t_min, t_max, t_out);
-        return rect_t(0, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, t_min, t_max, t_out);
+        if (kind == RT_PRIM_XY_RECT) return rect_t<true>(2, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, t_min, t_max, t_out);
+        if (kind == RT_PRIM_XZ_RECT) return rect_t<true>(1, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, t_min, t_max, t_out);
+        return rect_t<true>(0, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, t_min, t_max, t_out);
     }
     if (PRIMS == PRIMS_ANY) {
         if (P.flags & RT_PRIM_HAS_TRANSLATE) o = o - ld3(P.tr);
@@ -235,9 +247,9 @@ __device__ __forceinline__ bool prim_t(const Prim &P, d3 o, d3 d, d3 inv_d, doub
         t_out = root;
         return true;
     }
-    case RT_PRIM_XY_RECT: return rect_t(2, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, t_min, t_max, t_out);
-    case RT_PRIM_XZ_RECT: return rect_t(1, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, t_min, t_max, t_out);
-    case RT_PRIM_YZ_RECT: return rect_t(0, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, t_min, t_max, t_out);
+    case RT_PRIM_XY_RECT: return rect_t<true>(2, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, t_min, t_max, t_out);
+    case RT_PRIM_XZ_RECT: return rect_t<true>(1, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, t_min, t_max, t_out);
+    case RT_PRIM_YZ_RECT: return rect_t<true>(0, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, t_min, t_max, t_out);
     default: { // box.rs:82-101
         bool any = false;
         double closest = t_max;
@@ -246,7 +258,7 @@ __device__ __forceinline__ bool prim_t(const Prim &P, d3 o, d3 d, d3 inv_d, doub
             int axis;
             double a0, a1, b0, b1, k, t;
             box_side(P.p, s, axis, a0, a1, b0, b1, k);
-            if (rect_t(axis, a0, a1, b0, b1, k, o, d, inv_d, t_min, closest, t)) {
+            if (rect_t<false>(axis, a0, a1, b0, b1, k, o, d, inv_d, t_min, closest, t)) {
                 closest = t;
                 aux = s;
                 any = true;
