@@ -124,6 +124,22 @@ __device__ __forceinline__ bool coop_random_in_unit_sphere(bool need, uint32_t p
         const int n = __popcll(pending);
         // group size q = 2^lg, the largest power of two with n * q <= 64
         const int lg = n > 32 ? 0 : (n > 16 ? 1 : (n > 8 ? 2 : (n > 4 ? 3 : (n > 2 ? 4 : (n > 1 ? 5 : 6)))));
+        if (lg == 0) { // more than 32 requests: one candidate each, so every lane tests its OWN (no LDS, no shuffle)
+            if (need) {
+                const u4 b0 = philox4x32(pixel, sample, (seg << 8) | RT_RNG_SCATTER, 2u * base, k0, k1);
+                const u4 b1 = philox4x32(pixel, sample, (seg << 8) | RT_RNG_SCATTER, 2u * base + 1u, k0, k1);
+                const d3 p = mk(sym53(b0.a, b0.b), sym53(b0.c, b0.d), sym53(b1.a, b1.b));
+                if (len2(p) < 1.0) {
+                    result = p;
+                    need = false;
+                    have = true;
+                } else {
+                    base += 1u;
+                }
+            }
+            pending = __ballot(need);
+            continue;
+        }
         const int rank = lane_rank(pending);
         if (need) req[rank] = make_uint4(pixel, sample, seg, base);
         const int j = lane >> lg;              // request served by this lane
@@ -165,6 +181,21 @@ __device__ __forceinline__ void coop_random_in_unit_disk(bool need, uint32_t pix
     while (pending != 0) {
         const int n = __popcll(pending);
         const int lg = n > 32 ? 0 : (n > 16 ? 1 : (n > 8 ? 2 : (n > 4 ? 3 : (n > 2 ? 4 : (n > 1 ? 5 : 6)))));
+        if (lg == 0) { // one candidate per request: every lane tests its own (the usual first round of a batch)
+            if (need) {
+                const u4 b = philox4x32(pixel, sample, RT_RNG_LENS, base, k0, k1);
+                const double x = sym53(b.a, b.b), y = sym53(b.c, b.d);
+                if (x * x + y * y < 1.0) {
+                    out_x = x;
+                    out_y = y;
+                    need = false;
+                } else {
+                    base += 1u;
+                }
+            }
+            pending = __ballot(need);
+            continue;
+        }
         const int rank = lane_rank(pending);
         if (need) req[rank] = make_uint4(pixel, sample, 0u, base);
         const int j = lane >> lg;
