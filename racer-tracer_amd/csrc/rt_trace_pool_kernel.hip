@@ -49,7 +49,7 @@
 #include "rt_trace_common.h"
 
 #ifndef RT_OCC_TEX
-#define RT_OCC_TEX 3
+#define RT_OCC_TEX 4 // textured spheres-only / rects-only variants: 40 KB of LDS per block still fits four (C4 +3 %)
 #endif
 #ifndef RT_OCC_SPEC
 #define RT_OCC_SPEC 5
@@ -225,7 +225,7 @@ __device__ __forceinline__ void coop_random_in_unit_disk(bool need, uint32_t pix
 // BVH: closest hit through the skip-link hierarchy instead of the linear loop
 // (instantiated for PRIMS_ANY only; chosen for scenes with many primitives).
 template <int PRIMS, bool TEXTURED, bool SPECULAR, bool BVH>
-__global__ __launch_bounds__(256, TEXTURED ? RT_OCC_TEX : ((BVH || PRIMS == PRIMS_ANY) ? 4 : (SPECULAR ? RT_OCC_SPEC : 5))) void k_trace_pool_f64(const TraceArgs A) {
+__global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TEX) : ((BVH || PRIMS == PRIMS_ANY) ? 4 : (SPECULAR ? RT_OCC_SPEC : 5))) void k_trace_pool_f64(const TraceArgs A) {
     // Two batches of camera samples stay ahead of the hand-out, so that it may straddle a batch
     // boundary; the BVH variants keep one (their node array wants the LDS: three resident blocks
     // instead of two on the `random` scene) and a hand-out stops at the end of its batch.
