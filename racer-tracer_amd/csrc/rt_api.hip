@@ -494,6 +494,7 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
         q.flags = p.flags & (RT_PRIM_HAS_ROTATE_Y | RT_PRIM_HAS_TRANSLATE);
         q.material = p.material;
         q.inv_radius = (p.kind == RT_PRIM_SPHERE || p.kind == RT_PRIM_MOVING_SPHERE) ? 1.0 / p.p[3] : 0.0;
+        q.radius2 = p.p[3] * p.p[3];
         if (p.kind == RT_PRIM_MOVING_SPHERE) { // device packing: tr = pos_b - pos_a, rot_sin = time_a, rot_cos = 1/(time_b - time_a)
             for (int k = 0; k < 3; ++k) q.tr[k] = p.center_b[k] - p.p[k];
             q.rot_sin = p.time_a;

@@ -32,7 +32,8 @@ struct alignas(16) Prim { // 192 B
     int32_t material;
     int32_t _pad0;
     double inv_radius;    // sphere: 1.0 / radius (sphere.rs:61 divides via reciprocal)
-    double _pad1[2];
+    double radius2;       // sphere: radius * radius (sphere.rs:43), formed once at upload
+    double _pad1;
     // The primitive's material, copied in at upload (scene.rs:74-76: a SceneObject owns its
     // material): shading the winning primitive is then ONE round of per-lane loads instead of
     // the dependent chain primitive -> material index -> material record.

@@ -235,7 +235,7 @@ __device__ __forceinline__ bool prim_t(const Prim &P, d3 o, d3 d, d3 inv_d, doub
         d3 oc = o - center;
         double a = len2(d);
         double half_b = dot(oc, d);
-        double c = len2(oc) - P.p[3] * P.p[3];
+        double c = len2(oc) - P.radius2;
         double disc = half_b * half_b - a * c;
         if (disc < 0.0) return false;
         double sqrtd = sqrt(disc);
