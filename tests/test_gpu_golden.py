@@ -63,6 +63,30 @@ def test_noise_and_textures_full_resolution_band(rt, host, orc, gpu):
     assert float((d.max(axis=-1) > TIGHT).mean()) < 2e-3
 
 
+def test_three_balls_full_resolution_band(rt, host, orc, gpu):
+    """BASELINE config 2 at full size (1920x1080, aperture 0.1: the lens disk through the batched
+    cooperative sampler; glass incl. the negative-radius sphere; metal), reduced spp, against
+    the live oracle on bands of rows through the spheres."""
+    s = host.Session(os.path.join(ROOT, "scenes", "config_c2.yml"),
+                     scene=os.path.join(ROOT, "scenes", "three_balls.yml"))
+    p = s.params
+    assert (p.width, p.height) == (1920, 1080)
+    p.samples = 6
+    scene = rt.Scene(s)
+    try:
+        got = scene.render_frame(s.camera, p)
+        stats = scene.last_stats()
+    finally:
+        scene.close()
+    p.strip_rows, p.strip_count, p.strip_index = 8, 27, 17     # every 27th strip: 5 bands of 8 rows
+    ref, ref_segs = orc.render(s.desc, s.camera, p)
+    rows = ((np.arange(p.height) // 8) % 27) == 17
+    d = np.abs(ref[rows] - got[rows])
+    assert d.max() < TOL
+    assert float((d.max(axis=-1) > TIGHT).mean()) < 2e-3
+    assert 1.5 < stats.segments / stats.samples < 2.5
+
+
 def test_render_to_png_end_to_end(rt, host, gpu, tmp_path):
     """renderer -> tone map -> SavePng, as main.rs:148-158 wires it."""
     from PIL import Image
