@@ -114,6 +114,27 @@ def pmc_traffic(workload, spp, world):
     return table.get("%s:%d" % (workload, spp))
 
 
+def pmc_valu(workload, spp, world, kernel_ms, segments):
+    """VALU view of the trace kernel from the committed PMC summary of the SAME workload
+    (profiles/r01_c3_pmc_summary.json, rocprofv3 --pmc SQ_* in their own pass): the kernel is
+    VALU-issue bound, so this - not the HBM fraction - says how busy the chip really is."""
+    path = os.path.join(ROOT, "profiles", "r01_%s_pmc_summary.json" % workload)
+    if world != 1 or spp != 1024 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        summary = json.load(f)
+    kernels = [k for k in summary if "k_trace_pool_f64" in k]
+    if len(kernels) != 1 or "SQ_INSTS_VALU" not in summary[kernels[0]]:
+        return None
+    c = summary[kernels[0]]
+    simd_cycles = kernel_ms * 1e-3 * 2.4e9 * 1024   # 256 CUs x 4 SIMDs at 2.4 GHz (MI355X_MICROARCH.md)
+    return {"insts": c["SQ_INSTS_VALU"]["mean"],
+            "insts_per_segment": round(c["SQ_INSTS_VALU"]["mean"] / segments, 3),
+            "busy_frac": round(4.0 * c["SQ_ACTIVE_INST_VALU"]["mean"] / simd_cycles, 3),
+            "lanes_per_inst": round(c["SQ_THREAD_CYCLES_VALU"]["mean"] / c["SQ_ACTIVE_INST_VALU"]["mean"], 1),
+            "source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU, profiles/r01_%s_pmc_summary.json" % workload}
+
+
 def main():
     args = parse()
     import torch
@@ -241,6 +262,9 @@ def main():
             out["roofline"]["traffic"] = round(pmc["bytes_per_launch"] / (k_ms * 1e-3) / 1e9, 3)
             out["roofline"]["traffic_bytes_per_launch"] = pmc["bytes_per_launch"]
             out["roofline"]["traffic_source"] = pmc["source"]
+        valu = pmc_valu(args.workload, spp, world, k_ms, seg_per_step)
+        if valu is not None:
+            out["roofline"]["valu"] = valu
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(session, args.cpu_seconds)
         if rehearsal:
