@@ -265,7 +265,12 @@ typedef struct RtRenderStats {
 typedef void (*RtTileCallback)(void *user, const double *rgb, int32_t r, int32_t c,
                                int32_t width, int32_t height);
 
-/* --------------------------------------------------------------- functions */
+/* --------------------------------------------------------------- functions
+ * Threading (renderer.rs:101: `trait Renderer: Send + Sync`, called from one rayon worker at a
+ * time, main.rs:163-199): the library keeps no global state besides the thread-local error text.
+ * Different RtScene objects may be used from different threads concurrently; calls on the SAME
+ * RtScene must be serialised by the caller (the reference's render task does: one render at a
+ * time, scene rebuilt between renders).  Callbacks run on the calling thread. */
 
 /* ABI version of the loaded library (== RT_ABI_VERSION of its build). */
 int rt_abi_version(void);
