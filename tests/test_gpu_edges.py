@@ -147,3 +147,43 @@ def test_noise_with_identity_and_shuffled_permutations(rt, orc, gpu, shuffled):
     bundle, cam = _noise_scene(shuffled)
     got, ref, _, _ = _parity(rt, orc, bundle, cam, 96, 54, 6)
     assert got.std() > 0.05
+
+
+def test_two_scenes_from_two_threads(rt, orc, gpu):
+    """rt_abi.h threading contract: different RtScene objects may be used from different threads
+    at once (ctypes drops the GIL during the calls); each must get the frame it gets alone."""
+    import threading
+    jobs = []
+    for scene_fn, (w, h, spp) in ((S.cornell_box, (160, 90, 24)), (S.three_balls, (128, 72, 16))):
+        bundle, cam, _ = scene_fn()
+        jobs.append((bundle, S.camera_for(cam, w, h), S.abi.render_params(w, h, spp)))
+    alone = []
+    for bundle, camera, params in jobs:
+        scene = rt.Scene(bundle)
+        try:
+            alone.append(scene.render_frame(camera, params))
+        finally:
+            scene.close()
+    together = [None] * len(jobs)
+    errors = []
+
+    def work(k):
+        try:
+            bundle, camera, params = jobs[k]
+            scene = rt.Scene(bundle)
+            try:
+                for _ in range(3):
+                    together[k] = scene.render_frame(camera, params)
+            finally:
+                scene.close()
+        except Exception as e:  # noqa: BLE001 - reported below
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for a, b in zip(alone, together):
+        assert np.array_equal(a, b)
