@@ -10,7 +10,7 @@ region starts.  Rank 0 prints ONE JSON line.
 
 Default workload = BASELINE.json configs[2] (cornell_box.yml, 1920x1080, 1024
 spp, max_depth 20, Aces): it is the configuration the north star's target is
-quoted on and it fits one GPU.  `--workload c2|c4` select configs[1]/[3].
+quoted on and it fits one GPU.  `--workload c2|c4|c5` select configs[1]/[3]/[4].
 
 Scaling is STRONG: the frame is fixed, N GPUs split its rows (8-row strips,
 interleaved), so value = W*H*spp / time-of-the-slowest-rank.
@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4"])
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -48,6 +48,7 @@ def load_workload(host, name, spp_override):
         "c2": ("three_balls.yml", "config_c2.yml"),
         "c3": ("cornell_box.yml", "config_c3.yml"),
         "c4": ("noise_and_textures.yml", "config_c4.yml"),
+        "c5": ("cornell_box.yml", "config_c5.yml"),   # configs[4]: 3840x2160x4096, meant for 8 GPUs
     }
     scene_file, config_file = table[name]
     session = host.Session(os.path.join(ROOT, "scenes", config_file),
@@ -222,7 +223,7 @@ def main():
         k_ms = kernel_total_ms / args.steps
         achieved = BYTES_PER_SEGMENT_F64 * seg_per_step / (k_ms * 1e-3) / 1e9 / world  # GB/s per GPU
         out = {
-            "metric": "Msamples/s (W*H*spp/s) at 1920x1080",
+            "metric": "Msamples/s (W*H*spp/s) at %dx%d" % (W, H),
             "value": round(value, 2),
             "unit": "Msamples/s",
             "n_gpus": world,
