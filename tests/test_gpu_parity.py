@@ -158,7 +158,7 @@ def test_cancel_during_render_returns_ok_and_stops_the_tile_stream(rt, orc, gpu)
     import threading
     import time
     bundle, cam, _ = S.cornell_box()
-    w, h, spp = 1920, 1080, 2048            # ~0.3 s of GPU work: 10 tile columns x 3 sample batches
+    w, h, spp = 1920, 1080, 8192            # ~0.85 s of GPU work: 10 tile columns x 3 sample batches
     camera = S.camera_for(cam, w, h)
     params = S.abi.render_params(w, h, spp)
     scene = rt.Scene(bundle)
@@ -173,7 +173,7 @@ def test_cancel_during_render_returns_ok_and_stops_the_tile_stream(rt, orc, gpu)
         timer.join()
         assert flag.value == 1
         assert len(tiles) < 100                                     # the stream stopped ...
-        assert elapsed < 0.25                                       # ... early (a full render takes ~0.3 s)
+        assert elapsed < 0.6                                        # ... early (a full render takes ~0.85 s)
         # what was delivered is a prefix of the column-major tile list (cpu.rs:91-113)
         expect = [(108 * hs, 192 * ws) for ws in range(10) for hs in range(10)]
         assert [(t[0], t[1]) for t in tiles] == expect[:len(tiles)]
