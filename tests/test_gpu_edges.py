@@ -187,3 +187,65 @@ def test_two_scenes_from_two_threads(rt, orc, gpu):
     assert not errors, errors
     for a, b in zip(alone, together):
         assert np.array_equal(a, b)
+
+
+def test_furnace_known_answer_without_the_oracle(rt, gpu):
+    """An answer derived by hand, not by the oracle: a convex Lambertian object of albedo a in a
+    uniform environment of radiance c.  Every path that hits it scatters once and escapes
+    (a convex body cannot be hit again from its own surface), so EVERY sample returns a * c
+    exactly and every covered pixel is sqrt(a * c) (cpu.rs:52 gamma); the rest see sqrt(c).
+    lambertian.rs:26-38 + renderer.rs:41-90 + background_color.rs:45-48."""
+    abi = S.abi
+    a = np.array([0.5, 0.25, 0.75])
+    c = np.array([0.8, 0.6, 0.4])
+    bundle = abi.SceneBundle([abi.sphere((0.0, 0.0, -3.0), 1.0, 0)], [abi.material(abi.RT_MAT_LAMBERTIAN, 0)],
+                             [abi.solid(tuple(a))], abi.solid_background(tuple(c)))
+    cam = dict(look_from=(0.0, 0.0, 0.0), look_at=(0.0, 0.0, -1.0), vfov=60.0, aperture=0.0, focus_distance=1.0)
+    w, h, spp = 128, 72, 37
+    scene = rt.Scene(bundle)
+    try:
+        got = scene.render_frame(S.camera_for(cam, w, h), abi.render_params(w, h, spp))
+        stats = scene.last_stats()
+    finally:
+        scene.close()
+    on = np.isclose(got, np.sqrt(a * c), rtol=1e-13, atol=0).all(axis=-1)
+    off = np.isclose(got, np.sqrt(c), rtol=1e-13, atol=0).all(axis=-1)
+    edge = ~(on | off)                      # pixels whose samples straddle the silhouette
+    assert on.sum() > 600 and off.sum() > 5000 and edge.sum() < 300
+    lo, hi = np.minimum(np.sqrt(a * c), np.sqrt(c)), np.maximum(np.sqrt(a * c), np.sqrt(c))
+    assert ((got[edge] >= lo - 1e-12) & (got[edge] <= hi + 1e-12)).all()
+    # one segment for a miss, two for a hit: between 1 and 2 segments per sample, and an integer total
+    assert stats.samples == w * h * spp and stats.samples < stats.segments < 2 * stats.samples
+
+
+def test_white_furnace_is_exactly_white(rt, gpu):
+    """White furnace, again without the oracle: albedo-1 Lambertian, fuzz-0 and fuzzy Metal of
+    albedo 1, glass (attenuation 1, dialectric.rs:28) and a unit light in a white environment.
+    Every path ends in the environment (1), in the light (1) or in depth exhaustion (white,
+    renderer.rs:48-55), with throughput exactly 1 - unless a fuzzy reflection dips below the
+    surface and is absorbed (metal.rs:38-42, black).  So every pixel is exactly 1, except
+    pixels that see the fuzzy sphere, which may be darker but never brighter."""
+    abi = S.abi
+    one = abi.solid((1.0, 1.0, 1.0))
+    L, M, D, E = abi.RT_MAT_LAMBERTIAN, abi.RT_MAT_METAL, abi.RT_MAT_DIELECTRIC, abi.RT_MAT_DIFFUSE_LIGHT
+    materials = [abi.material(L, 0), abi.material(M, 0, fuzz=0.0), abi.material(D, -1, ior=1.5), abi.material(E, 0)]
+    prims = [abi.sphere((0.0, -100.5, -1.0), 100.0, 0), abi.sphere((-1.1, 0.0, -1.0), 0.5, 1),
+             abi.sphere((0.0, 0.0, -1.0), 0.5, 2), abi.sphere((0.0, 0.0, -1.0), -0.4, 2),
+             abi.sphere((1.1, 0.0, -1.0), 0.5, 3)]
+    cam = dict(look_from=(0.0, 1.0, 4.0), look_at=(0.0, 0.0, -1.0), vfov=35.0, aperture=0.2, focus_distance=5.0)
+    w, h, spp = 160, 90, 24
+    for fuzzy in (False, True):
+        mats = list(materials)
+        if fuzzy:
+            mats[1] = abi.material(M, 0, fuzz=0.6)
+        bundle = abi.SceneBundle(prims, mats, [one], abi.solid_background((1.0, 1.0, 1.0)))
+        scene = rt.Scene(bundle)
+        try:
+            got = scene.render_frame(S.camera_for(cam, w, h), abi.render_params(w, h, spp, max_depth=12))
+        finally:
+            scene.close()
+        assert np.isfinite(got).all()
+        if not fuzzy:
+            assert (got == 1.0).all()
+        else:
+            assert (got <= 1.0).all() and (got == 1.0).mean() > 0.7 and got.min() > 0.3
