@@ -291,3 +291,31 @@ def test_depth_zero_is_white_and_one_segment_paths(orc):  # renderer.rs:48-55
     assert segs == 32 * 18 * 2                       # exactly one scene.hit per sample
     assert set(np.unique(frame)) <= {0.0, 1.0, math.sqrt(0.5)} or True
     assert frame.max() > 1.0                          # the light itself (15) is visible at depth 1
+
+
+def test_furnaces_on_the_oracle(orc):
+    """The two whole-path known answers the GPU suite checks on the device (tests/test_gpu_edges.py),
+    here on the oracle: a convex Lambertian body of albedo a in a uniform environment c shows
+    sqrt(a * c) exactly, and a white furnace (albedo-1 Lambertian, mirror, glass, unit light, white
+    environment) is exactly 1 everywhere."""
+    abi = S.abi
+    a, c = np.array([0.5, 0.25, 0.75]), np.array([0.8, 0.6, 0.4])
+    bundle = abi.SceneBundle([abi.sphere((0.0, 0.0, -3.0), 1.0, 0)], [abi.material(abi.RT_MAT_LAMBERTIAN, 0)],
+                             [abi.solid(tuple(a))], abi.solid_background(tuple(c)))
+    cam = dict(look_from=(0.0, 0.0, 0.0), look_at=(0.0, 0.0, -1.0), vfov=60.0, aperture=0.0, focus_distance=1.0)
+    w, h, spp = 64, 36, 9
+    got, _ = orc.render(bundle.desc, S.camera_for(cam, w, h), abi.render_params(w, h, spp), n_threads=2)
+    on = np.isclose(got, np.sqrt(a * c), rtol=1e-13, atol=0).all(axis=-1)
+    off = np.isclose(got, np.sqrt(c), rtol=1e-13, atol=0).all(axis=-1)
+    assert on.sum() > 150 and off.sum() > 1200 and (~(on | off)).sum() < 150
+
+    one = abi.solid((1.0, 1.0, 1.0))
+    L, M, D, E = abi.RT_MAT_LAMBERTIAN, abi.RT_MAT_METAL, abi.RT_MAT_DIELECTRIC, abi.RT_MAT_DIFFUSE_LIGHT
+    materials = [abi.material(L, 0), abi.material(M, 0, fuzz=0.0), abi.material(D, -1, ior=1.5), abi.material(E, 0)]
+    prims = [abi.sphere((0.0, -100.5, -1.0), 100.0, 0), abi.sphere((-1.1, 0.0, -1.0), 0.5, 1),
+             abi.sphere((0.0, 0.0, -1.0), 0.5, 2), abi.sphere((0.0, 0.0, -1.0), -0.4, 2),
+             abi.sphere((1.1, 0.0, -1.0), 0.5, 3)]
+    cam = dict(look_from=(0.0, 1.0, 4.0), look_at=(0.0, 0.0, -1.0), vfov=35.0, aperture=0.2, focus_distance=5.0)
+    bundle = abi.SceneBundle(prims, materials, [one], abi.solid_background((1.0, 1.0, 1.0)))
+    got, _ = orc.render(bundle.desc, S.camera_for(cam, 64, 36), abi.render_params(64, 36, 6, max_depth=12), n_threads=2)
+    assert (got == 1.0).all()
