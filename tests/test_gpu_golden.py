@@ -63,6 +63,29 @@ def test_noise_and_textures_full_resolution_band(rt, host, orc, gpu):
     assert float((d.max(axis=-1) > TIGHT).mean()) < 2e-3
 
 
+def test_config3_at_full_size_and_full_spp_on_a_band(rt, host, orc, gpu):
+    """BASELINE config 3 exactly as benchmarked (cornell_box 1920x1080, 1024 spp, depth 20): the
+    device renders the whole frame, the oracle one 8-row band through the box;
+    32 sample chunks summed per pixel against the oracle's one running sum."""
+    s = host.Session(os.path.join(ROOT, "scenes", "config_c3.yml"), scene=os.path.join(ROOT, "scenes", "cornell_box.yml"))
+    p = s.params
+    assert (p.width, p.height, p.samples, p.max_depth) == (1920, 1080, 1024, 20)
+    scene = rt.Scene(s)
+    try:
+        got = scene.render_frame(s.camera, p)
+        stats = scene.last_stats()
+    finally:
+        scene.close()
+    assert stats.samples == 1920 * 1080 * 1024
+    p.strip_rows, p.strip_count, p.strip_index = 8, 135, 40          # rows 320..327: back wall, side walls, floor bounce
+    ref, _ = orc.render(s.desc, s.camera, p)
+    rows = ((np.arange(p.height) // 8) % 135) == 40
+    d = np.abs(ref[rows] - got[rows])
+    assert d.max() < TOL
+    assert float((d.max(axis=-1) > TIGHT).mean()) < 2e-3
+    assert got[rows].max() > 0.4 and (got[rows] > 0).mean() > 0.4      # the band crosses the lit box
+
+
 def test_three_balls_full_resolution_band(rt, host, orc, gpu):
     """BASELINE config 2 at full size (1920x1080, aperture 0.1: the lens disk through the batched
     cooperative sampler; glass incl. the negative-radius sphere; metal), reduced spp, against
