@@ -249,3 +249,28 @@ def test_white_furnace_is_exactly_white(rt, gpu):
             assert (got == 1.0).all()
         else:
             assert (got <= 1.0).all() and (got == 1.0).mean() > 0.7 and got.min() > 0.3
+
+
+@pytest.mark.parametrize("scene_fn", [S.three_balls, S.cornell_box, S.cornell_box_boxes])
+def test_v1_kernel_still_matches_the_oracle(rt, orc, gpu, scene_fn, monkeypatch):
+    """RT_TRACE_KERNEL=v1 selects the lane-per-pixel kernel, the second implementation
+    of the same contract: it must agree with the oracle, and with the pooled kernel to rounding."""
+    bundle, cam, _ = scene_fn()
+    w, h, spp = 96, 54, 12
+    camera = S.camera_for(cam, w, h)
+    params = S.abi.render_params(w, h, spp)
+    ref, ref_segs = orc.render(bundle.desc, camera, params, use_bvh=0)
+    frames = {}
+    for name in ("pool", "v1"):
+        if name == "v1":
+            monkeypatch.setenv("RT_TRACE_KERNEL", "v1")
+        scene = rt.Scene(bundle)
+        try:
+            frames[name] = scene.render_frame(camera, params)
+            segs = scene.last_stats().segments
+        finally:
+            scene.close()
+        d = np.abs(frames[name] - ref)
+        assert d.max() < TOL and (d > TIGHT).mean() < 2e-3, name
+        assert abs(int(segs) - ref_segs) <= 4
+    assert np.abs(frames["pool"] - frames["v1"]).max() < 1e-9
