@@ -311,7 +311,8 @@ int rt_render_frame_device(RtScene *scene, const RtCamera *camera,
  * it is non-zero the call returns RT_OK and emits nothing further; tiles
  * delivered before stay delivered (cpu.rs:55-62).  If it is already set on
  * entry the call returns RT_ERR_CANCEL_EVENT (cpu.rs:82-85).
- * rt_scene_last_stats after this call: kernel_ms spans all columns. */
+ * params->strip_count > 1 is refused (RT_ERR_INVALID_ARGUMENT): tiles are finished pieces of the
+ * frame.  rt_scene_last_stats after this call: kernel_ms spans all columns. */
 int rt_render(RtScene *scene, const RtCamera *camera, const RtRenderParams *params,
               RtTileCallback callback, void *user, const volatile int *cancel);
 

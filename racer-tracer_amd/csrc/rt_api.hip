@@ -651,6 +651,8 @@ int rt_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, RtTil
     int rc = check_params(camera, p);
     if (rc != RT_OK) return rc;
     if (p->tiles_w <= 0 || p->tiles_h <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "tile grid must be positive");
+    if (p->strip_count > 1) // a tile of the stream is a finished piece of the frame; row ownership is for rt_render_frame*
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_render delivers whole tiles: strip ownership is not supported here");
     if (cancel && *cancel) return RT_ERR_CANCEL_EVENT; // cpu.rs:82-85: prepare_threads fails with CancelEvent
     RT_HIP(hipSetDevice(s->device));
     const size_t n = (size_t)p->width * (size_t)p->height * 3;
@@ -682,8 +684,7 @@ int rt_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, RtTil
     // the tiles are bit-identical to rt_render_frame's.  The cancel flag is polled before
     // every launch and every callback; tiles delivered before it rose stay delivered, like
     // the reference's tiles that finished before the cancel (cpu.rs:55-62).
-    const bool progressive = !s->use_v1 && p->scale <= 1 && p->strip_count <= 1 && p->tiles_w > 1 &&
-                             width_step > 0;
+    const bool progressive = !s->use_v1 && p->scale <= 1 && p->tiles_w > 1 && width_step > 0;
     if (progressive) {
         int widest = 0;
         for (int ws = 0; ws < p->tiles_w; ++ws) widest = column_w(ws) > widest ? column_w(ws) : widest;
@@ -757,7 +758,7 @@ int rt_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, RtTil
         return RT_OK;
     }
 
-    // Whole-frame path (preview scale, strips, a single tile column, the v1 kernel): the
+    // Whole-frame path (preview scale, a single tile column, the v1 kernel): the
     // tiles are cut from the finished frame.  With a cancel flag, trace in batches so the
     // flag is polled about as often as the reference polls it per tile row (cpu.rs:55).
     int batch = 0;

@@ -274,3 +274,15 @@ def test_v1_kernel_still_matches_the_oracle(rt, orc, gpu, scene_fn, monkeypatch)
         assert d.max() < TOL and (d > TIGHT).mean() < 2e-3, name
         assert abs(int(segs) - ref_segs) <= 4
     assert np.abs(frames["pool"] - frames["v1"]).max() < 1e-9
+
+
+def test_tile_stream_refuses_strips(rt, gpu):
+    bundle, cam, _ = S.two_balls()
+    scene = rt.Scene(bundle)
+    try:
+        p = S.abi.render_params(32, 18, 2, tiles_w=2, tiles_h=2, strip_rows=8, strip_count=2, strip_index=0)
+        with pytest.raises(rt.RtError) as e:
+            scene.render_tiles(S.camera_for(cam, 32, 18), p)
+        assert e.value.code == S.abi.RT_ERR_INVALID_ARGUMENT
+    finally:
+        scene.close()
