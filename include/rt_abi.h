@@ -329,7 +329,9 @@ int rt_post_rgba8_device(RtScene *scene, const RtToneMap *tone_map, const double
                          size_t n_pixels, uint8_t *rgba_device, double *mapped_device, void *hip_stream);
 
 /* rt_render_frame + rt_post_rgba8_device + copy: out_rgba is HOST memory,
- * width*height*4 bytes (what SavePng hashes and encodes). */
+ * width*height*4 bytes (what SavePng hashes and encodes).  Whole frames only
+ * (params->strip_count > 1 is refused): with several GPUs gather the strips of
+ * rt_render_frame_device first and pack on the gathering rank with rt_post_rgba8_device. */
 int rt_render_frame_rgba8(RtScene *scene, const RtCamera *camera, const RtRenderParams *params,
                           const RtToneMap *tone_map, uint8_t *out_rgba);
 

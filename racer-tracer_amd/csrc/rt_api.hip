@@ -802,6 +802,8 @@ int rt_render_frame_rgba8(RtScene *s, const RtCamera *camera, const RtRenderPara
     if (!s || !tm || !out_rgba) return fail(RT_ERR_INVALID_ARGUMENT, "scene/tone_map/out is NULL");
     int rc = check_params(camera, p);
     if (rc != RT_OK) return rc;
+    if (p->strip_count > 1) // the packed frame is a whole picture; gather strips with rt_render_frame_device, then rt_post_rgba8_device
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_render_frame_rgba8 packs the whole frame: strip ownership is not supported here");
     RT_HIP(hipSetDevice(s->device));
     const size_t px = (size_t)p->width * (size_t)p->height;
     if (s->frame.count < px * 3) RT_HIP(s->frame.alloc(px * 3));
