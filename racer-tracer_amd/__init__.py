@@ -36,6 +36,14 @@ def lib():
             raise ImportError(
                 "%s is missing: build it with `make -C %s` (or __graft_entry__.build()); "
                 "there is no CPU fallback for the render path" % (LIB_PATH, _HERE))
+        # torch's ROCm wheels carry their own libamdhip64; whichever HIP runtime a process loads first
+        # serves everything after it, and torch cannot see the GPU through /opt/rocm's copy if this
+        # library pulled that in first (the other order is fine).  So a process that has torch loads
+        # torch's runtime first; one without torch (the C++/Rust hosts, the CLI) never notices.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = abi.bind(C.CDLL(LIB_PATH), abi.PROTOTYPES)
         if _lib.rt_abi_version() != abi.ABI_VERSION:
             raise ImportError("ABI version mismatch: library %d, binding %d"
