@@ -14,20 +14,38 @@ quoted on and it fits one GPU.  `--workload c2|c4|c5` select configs[1]/[3]/[4].
 
 Scaling is STRONG: the frame is fixed, N GPUs split its rows (8-row strips,
 interleaved), so value = W*H*spp / time-of-the-slowest-rank.
+
+`--gpus N` with N > 1 works both ways: under torch.distributed.run (RANK /
+WORLD_SIZE in the environment) this process is one rank; started plainly
+(`python bench.py --gpus N`) it spawns the N ranks as child processes BEFORE
+touching the GPU, relays rank 0's JSON line and exits with their status.
+
+roofline: the trace kernel keeps ray state in registers, so HBM is not what
+bounds it; the bound reported is VALU issue (SIMD cycles with a vector
+instruction executing, from rocprofv3 SQ counters of the same workload under
+profiles/, used only while their source stamp matches the kernel sources in the
+tree).  SURVEY 8(d)'s algorithmic-bytes figure is kept as `hbm_algorithmic`.
 """
 import argparse
-import ctypes as C
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from source_stamp import kernel_source_sha  # noqa: E402
+
 STRIP_ROWS = 8
+PMC_ROUND = "r02"              # profiles/<round>_<workload>_pmc_summary.json
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+SIMDS = 256 * 4                # 256 CUs x 4 SIMDs
+CLOCK_GHZ = 2.4                # MI355X_MICROARCH.md peak engine clock
 BYTES_PER_SEGMENT_F64 = 192.0  # SURVEY.md 8(d): 96-B f64 ray record read + written per segment
 
 
@@ -102,53 +120,101 @@ def cpu_baseline(session, seconds):
                       % (p.width, p.height, spp, dt, segs / n)}
 
 
-def pmc_traffic(workload, spp, world):
-    """HBM bytes per launch of the trace kernel, from the committed PMC summary
-    of the SAME workload (profiles/pmc_traffic.json, produced by
-    tools/gpu_pmc.sh + tools/pmc_to_traffic.py).  None when there is no
-    measurement for this exact configuration."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if world != 1 or not os.path.exists(path):
-        return None
-    with open(path) as f:
-        table = json.load(f)
-    return table.get("%s:%d" % (workload, spp))
-
-
-def pmc_valu(workload, spp, world, kernel_ms, segments):
-    """VALU view of the trace kernel from the committed PMC summary of the SAME workload
-    (profiles/r01_c3_pmc_summary.json, rocprofv3 --pmc SQ_* in their own pass): the kernel is
-    VALU-issue bound, so this - not the HBM fraction - says how busy the chip really is."""
-    path = os.path.join(ROOT, "profiles", "r01_%s_pmc_summary.json" % workload)
-    if world != 1 or spp != 1024 or not os.path.exists(path):
-        return None
+def pmc_summary(workload, workload_name, world):
+    """The committed rocprofv3 PMC summary of this workload's trace kernel (tools/gpu_pmc.sh ->
+    profiles/<round>_<workload>_pmc_summary.json), or (None, reason).  Refused when it was collected
+    on other kernel sources than the ones in the tree, on another frame, or for N > 1."""
+    path = os.path.join(ROOT, "profiles", "%s_%s_pmc_summary.json" % (PMC_ROUND, workload))
+    rel = os.path.relpath(path, ROOT)
+    if world != 1:
+        return None, "PMC passes are single-GPU"
+    if not os.path.exists(path):
+        return None, "no %s" % rel
     with open(path) as f:
         summary = json.load(f)
+    stamp = summary.get("_stamp", {})
+    if stamp.get("source_sha") != kernel_source_sha():
+        return None, "%s was collected on other kernel sources (stamp mismatch): re-run tools/gpu_pmc.sh" % rel
+    if stamp.get("workload") != workload_name:
+        return None, "%s is for %r" % (rel, stamp.get("workload"))
     kernels = [k for k in summary if "k_trace_pool_f64" in k]
-    if len(kernels) != 1 or "SQ_INSTS_VALU" not in summary[kernels[0]]:
+    if len(kernels) != 1:
+        return None, "%s holds %d trace kernels" % (rel, len(kernels))
+    return dict(summary[kernels[0]], _path=rel, _stamp=stamp), None
+
+
+def valu_roofline(c, kernel_ms, segments):
+    """VALU-issue view of one launch.  SQ_ACTIVE_INST_VALU counts, per SIMD, cycles/4 with a vector
+    instruction executing (MI355X_MICROARCH.md, SQ counters): x4 = busy SIMD-cycles.  Peak = every SIMD
+    busy every cycle of the LIVE kernel duration at the peak clock."""
+    busy_cycles = 4.0 * c["SQ_ACTIVE_INST_VALU"]["mean"]
+    secs = kernel_ms * 1e-3
+    achieved = busy_cycles / secs / 1e9
+    peak = SIMDS * CLOCK_GHZ
+    lanes = c["SQ_THREAD_CYCLES_VALU"]["mean"] / c["SQ_ACTIVE_INST_VALU"]["mean"]
+    return {"achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "G busy SIMD-cycles/s",
+            "frac": round(achieved / peak, 4),
+            "valu_insts_per_launch": c["SQ_INSTS_VALU"]["mean"],
+            "valu_insts_per_segment": round(c["SQ_INSTS_VALU"]["mean"] / segments, 3),
+            "lanes_per_inst": round(lanes, 1),
+            "useful_lane_frac": round(achieved / peak * lanes / 64.0, 4),
+            "kernel_ms_under_pmc": c["_stamp"].get("kernel_ms_under_pmc"),
+            "source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU (own pass), %s, "
+                      "source stamp %s" % (c["_path"], c["_stamp"]["source_sha"][:12])}
+
+
+def hbm_traffic(c):
+    """HBM bytes of one launch from the FETCH_SIZE / WRITE_SIZE passes, corrected as
+    MI355X_MICROARCH.md prescribes: units of 1 KiB, reads x2 on gfx950 (128-B requests counted as 64 B)."""
+    if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
         return None
-    c = summary[kernels[0]]
-    simd_cycles = kernel_ms * 1e-3 * 2.4e9 * 1024   # 256 CUs x 4 SIMDs at 2.4 GHz (MI355X_MICROARCH.md)
-    return {"insts": c["SQ_INSTS_VALU"]["mean"],
-            "insts_per_segment": round(c["SQ_INSTS_VALU"]["mean"] / segments, 3),
-            "busy_frac": round(4.0 * c["SQ_ACTIVE_INST_VALU"]["mean"] / simd_cycles, 3),
-            "lanes_per_inst": round(c["SQ_THREAD_CYCLES_VALU"]["mean"] / c["SQ_ACTIVE_INST_VALU"]["mean"], 1),
-            "source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU, profiles/r01_%s_pmc_summary.json" % workload}
+    return 2.0 * c["FETCH_SIZE"]["mean"] * 1024.0 + c["WRITE_SIZE"]["mean"] * 1024.0
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (nothing
+    in this process has touched the GPU), relay rank 0's JSON line, return the children's status."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.startswith("{") and line is None:
+            line = out
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks exited without a result line\n")
+        rc = 1
+    return rc
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))  # before torch / HIP are even imported
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
-                     "--nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: there is no CPU fallback for the render path")
+    if world > torch.cuda.device_count() and os.environ.get("BENCH_REHEARSE_ON_ONE_GPU") != "1":
+        sys.exit("bench.py --gpus %d: only %d device(s) visible (BENCH_REHEARSE_ON_ONE_GPU=1 runs a "
+                 "functional rehearsal of the N > 1 path on one card)" % (world, torch.cuda.device_count()))
     # BENCH_REHEARSE_ON_ONE_GPU=1: every rank uses device 0 and the collective goes
     # over gloo (RCCL cannot put several ranks on one card).  A functional rehearsal of
     # the N > 1 path for a 1-GPU box; its numbers mean nothing.
@@ -197,8 +263,10 @@ def main():
         step(False)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    for k in range(args.steps):
+        # reading the HIP events of a step waits for it: every step at N = 1 (the roofline's kernel time is
+        # the average over the timed region), only the last one at N > 1, where the host must run ahead
+        step(world == 1 or k == args.steps - 1)
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -215,13 +283,15 @@ def main():
     else:
         total_segments = float(sum(segments))
         kernel_total_ms = sum(kernel_ms)
+    recorded = len(kernel_ms)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = W * H * spp / (elapsed / args.steps) / 1e6
-        seg_per_step = total_segments / args.steps
-        k_ms = kernel_total_ms / args.steps
-        achieved = BYTES_PER_SEGMENT_F64 * seg_per_step / (k_ms * 1e-3) / 1e9 / world  # GB/s per GPU
+        seg_per_step = total_segments / recorded
+        k_ms = kernel_total_ms / recorded
+        algorithmic = BYTES_PER_SEGMENT_F64 * seg_per_step / (k_ms * 1e-3) / 1e9 / world  # GB/s per GPU
+        counters, why_not = pmc_summary(args.workload, workload, world)
         out = {
             "metric": "Msamples/s (W*H*spp/s) at %dx%d" % (W, H),
             "value": round(value, 2),
@@ -239,33 +309,34 @@ def main():
                        "parallelism": "image rows interleaved over %d GPU(s)%s"
                                       % (world, ", RCCL gather to rank 0" if world > 1 else "")},
             "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "bound": "valu",
+                "achieved": None, "peak": round(SIMDS * CLOCK_GHZ, 1), "unit": "G busy SIMD-cycles/s", "frac": None,
                 "traffic": None,
                 "kernel": "k_trace_pool_f64",
                 "kernel_ms": round(k_ms, 3),
                 "segments_per_launch": seg_per_step / world,
-                "bytes_per_segment": BYTES_PER_SEGMENT_F64,
-                "algorithmic_bytes_per_launch": BYTES_PER_SEGMENT_F64 * seg_per_step / world,
                 "gsegments_per_s": round(seg_per_step / (k_ms * 1e-3) / 1e9, 3),
-                "note": "achieved = algorithmic ray-state bytes (192 B/segment, SURVEY 8d) / kernel time; "
-                        "the kernel keeps ray state in registers, so its real HBM traffic is the per-chunk "
-                        "framebuffer slices only and frac can exceed 1",
+                "hbm_algorithmic": {
+                    "bytes_per_segment": BYTES_PER_SEGMENT_F64,
+                    "bytes_per_launch": BYTES_PER_SEGMENT_F64 * seg_per_step / world,
+                    "achieved": round(algorithmic, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(algorithmic / HBM_PEAK_GBS, 4),
+                    "note": "SURVEY 8(d): a 96-B f64 ray record read + written per segment, over the kernel "
+                            "time.  NOT a bound of this kernel: ray state lives in registers and is never "
+                            "streamed, so the figure can exceed 1; it says how the segment rate compares with "
+                            "the best an HBM-streaming wavefront tracer could reach (41.7 G segments/s)"},
             },
         }
-        pmc = pmc_traffic(args.workload, spp, world)
-        if pmc is not None:
-            # HBM bytes of one k_trace_pool_f64 launch from rocprofv3 PMC passes (tools/gpu_pmc.sh),
-            # corrected as MI355X_MICROARCH.md prescribes, over the live kernel duration
-            out["roofline"]["traffic"] = round(pmc["bytes_per_launch"] / (k_ms * 1e-3) / 1e9, 3)
-            out["roofline"]["traffic_bytes_per_launch"] = pmc["bytes_per_launch"]
-            out["roofline"]["traffic_source"] = pmc["source"]
-        valu = pmc_valu(args.workload, spp, world, k_ms, seg_per_step)
-        if valu is not None:
-            out["roofline"]["valu"] = valu
+        if counters is not None:
+            out["roofline"].update(valu_roofline(counters, k_ms, seg_per_step))
+            traffic = hbm_traffic(counters)
+            if traffic is not None:
+                # measured HBM bytes per launch over the live kernel duration
+                out["roofline"]["traffic"] = round(traffic / (k_ms * 1e-3) / 1e9, 3)
+                out["roofline"]["traffic_bytes_per_launch"] = traffic
+                out["roofline"]["traffic_frac_of_hbm_peak"] = round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        else:
+            out["roofline"]["counters_unavailable"] = why_not
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(session, args.cpu_seconds)
         if rehearsal:

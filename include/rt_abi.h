@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2
+#define RT_ABI_VERSION 3
 
 /* ------------------------------------------------------------------ errors
  * 0 = Ok.  1..22 are exactly the reference's exit codes
@@ -247,6 +247,28 @@ typedef struct RtToneMap {
 
 typedef struct RtScene RtScene; /* opaque; owned by the library */
 
+/* ------------------------------------------------------------ scene options
+ * Implementation choices rt_scene_create makes by itself, exposed so that a
+ * caller (the parity tests above all) can pin them.  Every combination renders
+ * the same picture: closest-hit semantics are those of bvh_node.rs:112-132 in
+ * all of them and the pooled and v1 kernels implement the same contract.  The
+ * library reads NO environment variable (developer builds with
+ * -DRT_DEVELOPER_KNOBS aside). */
+enum RtClosestHit {
+    RT_HIT_AUTO = 0,   /* linear loop up to 48 primitives, BVH above */
+    RT_HIT_LINEAR = 1, /* brute force over the primitive table (it lives in LDS: a few hundred primitives at most) */
+    RT_HIT_BVH = 2     /* skip-link BVH */
+};
+enum RtTraceKernel {
+    RT_KERNEL_POOL = 0, /* k_trace_pool_f64: persistent waves over a pool of paths (default) */
+    RT_KERNEL_V1 = 1    /* k_trace_f64: lane = pixel; the simple second implementation */
+};
+typedef struct RtSceneOptions {
+    int32_t closest_hit; /* RtClosestHit  */
+    int32_t kernel;      /* RtTraceKernel */
+    int32_t _reserved[6]; /* must be 0 */
+} RtSceneOptions;
+
 /* Statistics of the last render on a scene (path segments = ray_color
  * levels actually evaluated; feeds the roofline figure of bench.py). */
 typedef struct RtRenderStats {
@@ -283,6 +305,8 @@ int rt_device_count(void);
  * `&dyn BackgroundColor` to the renderer (renderer.rs:92-99); re-doable
  * because the reference rebuilds its BVH between renders (main.rs:178). */
 int rt_scene_create(const RtSceneDesc *desc, int device, RtScene **out);
+/* Same with explicit options (NULL = defaults = rt_scene_create). */
+int rt_scene_create_ex(const RtSceneDesc *desc, int device, const RtSceneOptions *options, RtScene **out);
 void rt_scene_destroy(RtScene *scene);
 
 /* Replaces `CpuRenderer::render` (renderer/cpu.rs:118-131) with the whole
@@ -334,6 +358,30 @@ int rt_post_rgba8_device(RtScene *scene, const RtToneMap *tone_map, const double
  * rt_render_frame_device first and pack on the gathering rank with rt_post_rgba8_device. */
 int rt_render_frame_rgba8(RtScene *scene, const RtCamera *camera, const RtRenderParams *params,
                           const RtToneMap *tone_map, uint8_t *out_rgba);
+
+/* ---------------------------------------------------------- several devices
+ * The reference shards one frame over its rayon pool by tile inside ONE call
+ * (renderer/cpu.rs:118-131); these do the same over the GPUs of one process.
+ * scenes[i] are RtScene objects of the SAME description created on the devices
+ * that should take part (a device may appear twice: two scenes on it share it).
+ * The frame is cut into strips of `strip_rows` rows (0 = 8), strip j belongs to
+ * scenes[j % n_scenes]; every device traces its strips concurrently on its own
+ * stream and the finished strips are collected
+ *   - rt_render_frame_multi:        straight into out_rgb (HOST memory), each
+ *     device copying its own strips over its own PCIe link;
+ *   - rt_render_frame_multi_device: into out_rgb_device, memory of
+ *     scenes[0]'s device, by peer copies over xGMI (one strided
+ *     hipMemcpy2DAsync per device on that device's stream; a single process
+ *     needs no RCCL rendezvous for that — the multi-PROCESS path gathers with
+ *     RCCL, racer-tracer_amd/strips.py).  Synchronises before returning.
+ * params->strip_* must be unset (the call sets them per device) and
+ * params->scale <= 1.  The frame is bit-identical to rt_render_frame's for
+ * every n_scenes (the RNG is addressed by the global pixel index).
+ * rt_scene_last_stats(scenes[i]) afterwards gives device i's share. */
+int rt_render_frame_multi(RtScene *const *scenes, int n_scenes, const RtCamera *camera,
+                          const RtRenderParams *params, int strip_rows, double *out_rgb);
+int rt_render_frame_multi_device(RtScene *const *scenes, int n_scenes, const RtCamera *camera,
+                                 const RtRenderParams *params, int strip_rows, double *out_rgb_device);
 
 /* Stats of the most recent render call on this scene (synchronises the
  * stream of that call first). */

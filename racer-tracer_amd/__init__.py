@@ -51,6 +51,16 @@ def lib():
     return _lib
 
 
+def load_library(path):
+    """Another build of the same ABI (e.g. build/libracer_tracer_amd_exact.so, the tests' exact-arithmetic
+    build) next to the default one: pass the result as Scene(..., library=...)."""
+    lib()  # the default library (and torch's HIP runtime) first
+    other = abi.bind(C.CDLL(path), abi.PROTOTYPES)
+    if other.rt_abi_version() != abi.ABI_VERSION:
+        raise ImportError("ABI version mismatch in %s" % path)
+    return other
+
+
 def _strerror(code):
     try:
         return lib().rt_strerror(code).decode()
@@ -58,28 +68,49 @@ def _strerror(code):
         return "?"
 
 
-def check(code, what):
+def check(code, what, library=None):
     if code != abi.RT_OK:
-        raise RtError(code, what, lib().rt_last_error_message().decode())
+        raise RtError(code, what, (library or lib()).rt_last_error_message().decode())
 
 
 def device_count():
     return lib().rt_device_count()
 
 
+def render_frame_multi(scenes, camera, params, strip_rows=0):
+    """rt_render_frame_multi: one frame over several Scene objects (one per device share)
+    -> float64 [H, W, 3] on the host."""
+    out = np.zeros((params.height, params.width, 3), dtype=np.float64)
+    handles = (C.c_void_p * len(scenes))(*[s._h for s in scenes])
+    check(lib().rt_render_frame_multi(handles, len(scenes), C.byref(camera), C.byref(params), strip_rows,
+                                      out.ctypes.data_as(C.POINTER(C.c_double))), "rt_render_frame_multi")
+    return out
+
+
+def render_frame_multi_device(scenes, camera, params, out_ptr, strip_rows=0):
+    """rt_render_frame_multi_device: out_ptr = device address (int) on scenes[0]'s device."""
+    handles = (C.c_void_p * len(scenes))(*[s._h for s in scenes])
+    check(lib().rt_render_frame_multi_device(handles, len(scenes), C.byref(camera), C.byref(params), strip_rows,
+                                             C.c_void_p(out_ptr)), "rt_render_frame_multi_device")
+
+
 class Scene:
     """RtScene handle: a scene uploaded to one GPU (rt_scene_create)."""
 
-    def __init__(self, desc, device=0):
+    def __init__(self, desc, device=0, closest_hit=abi.RT_HIT_AUTO, kernel=abi.RT_KERNEL_POOL, library=None):
+        """closest_hit / kernel: RtSceneOptions (rt_scene_create_ex) — implementation choices
+        the parity tests pin; the defaults are rt_scene_create's own.  library: load_library()."""
+        self._lib = library or lib()
         self._h = C.c_void_p()
         self._desc_owner = desc  # keep SceneBundle / host session alive
         d = desc.desc if hasattr(desc, "desc") else desc
-        check(lib().rt_scene_create(C.byref(d), device, C.byref(self._h)), "rt_scene_create")
+        opt = abi.RtSceneOptions(closest_hit, kernel)
+        check(self._lib.rt_scene_create_ex(C.byref(d), device, C.byref(opt), C.byref(self._h)), "rt_scene_create_ex", self._lib)
         self.device = device
 
     def close(self):
         if self._h:
-            lib().rt_scene_destroy(self._h)
+            self._lib.rt_scene_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -91,26 +122,26 @@ class Scene:
     def render_frame(self, camera, params):
         """rt_render_frame -> float64 [H, W, 3], gamma-encoded, not tone-mapped."""
         out = np.zeros((params.height, params.width, 3), dtype=np.float64)
-        check(lib().rt_render_frame(self._h, C.byref(camera), C.byref(params),
-                                    out.ctypes.data_as(C.POINTER(C.c_double))), "rt_render_frame")
+        check(self._lib.rt_render_frame(self._h, C.byref(camera), C.byref(params),
+                                    out.ctypes.data_as(C.POINTER(C.c_double))), "rt_render_frame", self._lib)
         return out
 
     def render_frame_device(self, camera, params, out_ptr, stream=None):
         """rt_render_frame_device: out_ptr = device address (int), stream = hipStream_t (int)."""
-        check(lib().rt_render_frame_device(self._h, C.byref(camera), C.byref(params),
+        check(self._lib.rt_render_frame_device(self._h, C.byref(camera), C.byref(params),
                                            C.c_void_p(out_ptr), C.c_void_p(stream or 0)),
               "rt_render_frame_device")
 
     def render_frame_rgba8(self, camera, params, tone_map):
         """rt_render_frame_rgba8 -> uint8 [H, W, 4]: render, tone-map and pack on the device."""
         out = np.zeros((params.height, params.width, 4), dtype=np.uint8)
-        check(lib().rt_render_frame_rgba8(self._h, C.byref(camera), C.byref(params), C.byref(tone_map),
-                                          out.ctypes.data_as(C.POINTER(C.c_uint8))), "rt_render_frame_rgba8")
+        check(self._lib.rt_render_frame_rgba8(self._h, C.byref(camera), C.byref(params), C.byref(tone_map),
+                                          out.ctypes.data_as(C.POINTER(C.c_uint8))), "rt_render_frame_rgba8", self._lib)
         return out
 
     def post_rgba8_device(self, tone_map, rgb_ptr, n_pixels, rgba_ptr, mapped_ptr=None, stream=None):
         """rt_post_rgba8_device on device addresses (ints)."""
-        check(lib().rt_post_rgba8_device(self._h, C.byref(tone_map), C.c_void_p(rgb_ptr), n_pixels,
+        check(self._lib.rt_post_rgba8_device(self._h, C.byref(tone_map), C.c_void_p(rgb_ptr), n_pixels,
                                          C.c_void_p(rgba_ptr), C.c_void_p(mapped_ptr or 0), C.c_void_p(stream or 0)),
               "rt_post_rgba8_device")
 
@@ -124,10 +155,10 @@ class Scene:
 
         cb = abi.RtTileCallback(on_tile)
         cancel_ptr = C.cast(cancel, C.POINTER(C.c_int)) if cancel is not None else None
-        check(lib().rt_render(self._h, C.byref(camera), C.byref(params), cb, None, cancel_ptr), "rt_render")
+        check(self._lib.rt_render(self._h, C.byref(camera), C.byref(params), cb, None, cancel_ptr), "rt_render", self._lib)
         return tiles
 
     def last_stats(self):
         st = abi.RtRenderStats()
-        check(lib().rt_scene_last_stats(self._h, C.byref(st)), "rt_scene_last_stats")
+        check(self._lib.rt_scene_last_stats(self._h, C.byref(st)), "rt_scene_last_stats", self._lib)
         return st

@@ -5,7 +5,7 @@ C header; tests/test_abi_layout.py checks the sizes against the C compiler.
 """
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # RtError (reference codes: racer-tracer/src/error.rs:71-97)
 RT_OK = 0
@@ -101,6 +101,14 @@ class RtToneMap(C.Structure):
                 ("aces_in", C.c_double * 9), ("aces_out", C.c_double * 9)]
 
 
+RT_HIT_AUTO, RT_HIT_LINEAR, RT_HIT_BVH = 0, 1, 2
+RT_KERNEL_POOL, RT_KERNEL_V1 = 0, 1
+
+
+class RtSceneOptions(C.Structure):
+    _fields_ = [("closest_hit", C.c_int32), ("kernel", C.c_int32), ("_reserved", C.c_int32 * 6)]
+
+
 RtTileCallback = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_int32,
                              C.c_int32, C.c_int32)
 
@@ -109,6 +117,7 @@ PROTOTYPES = {
     "rt_abi_version": (C.c_int, []),
     "rt_device_count": (C.c_int, []),
     "rt_scene_create": (C.c_int, [C.POINTER(RtSceneDesc), C.c_int, C.POINTER(C.c_void_p)]),
+    "rt_scene_create_ex": (C.c_int, [C.POINTER(RtSceneDesc), C.c_int, C.POINTER(RtSceneOptions), C.POINTER(C.c_void_p)]),
     "rt_scene_destroy": (None, [C.c_void_p]),
     "rt_render_frame": (C.c_int, [C.c_void_p, C.POINTER(RtCamera), C.POINTER(RtRenderParams),
                                   C.POINTER(C.c_double)]),
@@ -120,6 +129,10 @@ PROTOTYPES = {
                                        C.c_void_p, C.c_void_p]),
     "rt_render_frame_rgba8": (C.c_int, [C.c_void_p, C.POINTER(RtCamera), C.POINTER(RtRenderParams),
                                         C.POINTER(RtToneMap), C.POINTER(C.c_uint8)]),
+    "rt_render_frame_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(RtCamera),
+                                        C.POINTER(RtRenderParams), C.c_int, C.POINTER(C.c_double)]),
+    "rt_render_frame_multi_device": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(RtCamera),
+                                               C.POINTER(RtRenderParams), C.c_int, C.c_void_p]),
     "rt_scene_last_stats": (C.c_int, [C.c_void_p, C.POINTER(RtRenderStats)]),
     "rt_strerror": (C.c_char_p, [C.c_int]),
     "rt_last_error_message": (C.c_char_p, []),

@@ -11,8 +11,7 @@
 #include <string>
 #include <vector>
 #include "rt_bvh.h"
-#include "rt_device_types.h"
-#include "../../include/rt_abi.h"
+#include "rt_scene.h"
 
 extern "C" hipError_t rtdev_launch_trace(const rtdev::TraceArgs *args, int prims_class, int textured,
                                          int specular, hipStream_t stream);
@@ -29,86 +28,16 @@ extern "C" hipError_t rtdev_launch_resolve_chunks(const double *partial, double 
                                                   int cover_w, int cover_h, int x0, int x_count, int samples,
                                                   hipStream_t stream);
 
-namespace {
-
 thread_local std::string g_last_error;
 
-int fail(int code, const std::string &msg) {
+int rtapi::fail(int code, const std::string &msg) {
     g_last_error = msg;
     return code;
 }
+using rtapi::DevBuf;
+using rtapi::fail;
+using rtapi::Window;
 
-#define RT_HIP(call)                                                                        \
-    do {                                                                                    \
-        hipError_t e_ = (call);                                                             \
-        if (e_ != hipSuccess)                                                               \
-            return fail(RT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));     \
-    } while (0)
-
-template <class T> struct DevBuf {
-    T *ptr = nullptr;
-    size_t count = 0;
-    hipError_t alloc(size_t n) {
-        release();
-        if (n == 0) return hipSuccess;
-        hipError_t e = hipMalloc((void **)&ptr, n * sizeof(T));
-        if (e == hipSuccess) count = n;
-        return e;
-    }
-    void release() {
-        if (ptr) (void)hipFree(ptr);
-        ptr = nullptr;
-        count = 0;
-    }
-};
-
-} // namespace
-
-struct RtScene {
-    int device = 0;
-    DevBuf<rtdev::Prim> prims;
-    DevBuf<rtdev::Texture> textures;
-    DevBuf<rtdev::Image> images;
-    DevBuf<rtdev::Perlin> perlins;
-    std::vector<uint8_t *> image_pixels; // device copies of the RGBA8 texels
-    int n_prims = 0, n_materials = 0, n_textures = 0, n_images = 0, n_perlins = 0;
-    int perlin_identity = 1; // all permutation tables are the identity (noise.rs:121-130 never shuffles them)
-    rtdev::Background bg;
-    // kernel specialisation (rt_trace_kernel.hip): 0 rects only, 1 spheres only, 2 anything
-    int prims_class = 2;
-    int textured = 0; // some material's texture is not a plain SolidColor
-    int specular = 0; // some material is Metal or Dielectric
-
-    // closest hit: linear loop for small scenes, skip-link BVH (rt_bvh.h) above kBvhThreshold primitives
-    int use_bvh = 0;
-    DevBuf<rtdev::BvhNode> bvh_nodes;
-    DevBuf<int32_t> bvh_prim_index;
-    int n_bvh_nodes = 0;
-    bool bvh_nodes_in_lds = false; // node array (64 B each) staged in dynamic LDS when <= 32 KiB
-
-    // pooled kernel (default): persistent grid = CUs x resident blocks of the variant
-    bool use_v1 = false;   // env RT_TRACE_KERNEL=v1: the lane-per-pixel kernel
-    int num_cus = 0, pool_blocks_per_cu = 1;
-    DevBuf<double> partial;       // [chunks][H][W][3] per-chunk sums
-    DevBuf<unsigned int> queue;   // one item counter per launch of a render call
-    int last_chunks = 0;
-
-    DevBuf<double> accum;  // running sums, W*H*3 (v1 kernel)
-    DevBuf<double> frame;  // resolved frame for the host-output entry points
-    DevBuf<uint8_t> rgba;  // packed frame of rt_render_frame_rgba8
-    DevBuf<unsigned long long> segments;
-    hipStream_t stream = nullptr; // used by rt_render_frame / rt_render
-    hipEvent_t ev_begin = nullptr, ev_traced = nullptr, ev_resolved = nullptr;
-    // rt_render's progressive delivery: two pinned column buffers [height][column width][3]
-    // and the events that say a column's copy has landed
-    double *pinned[2] = {nullptr, nullptr};
-    size_t pinned_count[2] = {0, 0};
-    hipEvent_t ev_column[2] = {nullptr, nullptr};
-    hipStream_t last_stream = nullptr;
-    bool has_stats = false;
-    uint64_t last_samples = 0;
-    int last_launches = 0;
-};
 
 namespace {
 
@@ -178,7 +107,9 @@ template <class T> int upload(DevBuf<T> &buf, const std::vector<T> &host) {
     return RT_OK;
 }
 
-int check_params(const RtCamera *camera, const RtRenderParams *p) {
+} // namespace
+
+int rtapi::check_params(const RtCamera *camera, const RtRenderParams *p) {
     if (!camera || !p) return fail(RT_ERR_INVALID_ARGUMENT, "camera/params is NULL");
     // cpu.rs:36,40 divide by (W - 1) and (H - 1): a one-pixel dimension is a division by zero in the
     // reference (inf/NaN rays, an undefined picture); it is refused here instead of imitated
@@ -194,6 +125,9 @@ int check_params(const RtCamera *camera, const RtRenderParams *p) {
     }
     return RT_OK;
 }
+using rtapi::check_params;
+
+namespace {
 
 void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtdev::TraceArgs &a) {
     memset(&a, 0, sizeof a);
@@ -263,25 +197,19 @@ void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtd
     a.bvh_prim_index = s->bvh_prim_index.ptr;
     a.n_bvh_nodes = s->n_bvh_nodes;
     a.bvh_lds_nodes = s->bvh_nodes_in_lds ? s->n_bvh_nodes : 0;
+#ifdef RT_DEVELOPER_KNOBS // throw-away kernel knobs of the developer build (tools/perf_ab.sh)
     for (int k = 0; k < 4; ++k) {
         char name[16];
         snprintf(name, sizeof name, "RT_DBG%d", k);
         if (const char *v = getenv(name)) a.dbg[k] = atoi(v);
     }
+#endif
 }
 
-// Column window of a progressive render: pixel columns [x0, x0 + width) of every
-// row, `index` of `count` windows of one rt_render call (the segment counter and the
-// begin event belong to the first, the item-counter slots to all of them).
-struct Window {
-    int x0 = 0, width = 0; // width 0 = the whole frame
-    int index = 0, count = 1;
-};
+} // namespace
 
-// Enqueue trace (in sample batches, polling `cancel` between them) + resolve.
-// Returns RT_ERR_CANCEL_EVENT when cancelled (callers map that to RT_OK).
-int enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, double *out_device,
-                   hipStream_t stream, int batch, const volatile int *cancel, const Window &win = Window()) {
+int rtapi::enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, double *out_device,
+                          hipStream_t stream, int batch, const volatile int *cancel, const Window &win) {
     RT_HIP(hipSetDevice(s->device));
     size_t n = (size_t)p->width * (size_t)p->height * 3;
     rtdev::TraceArgs a;
@@ -324,8 +252,10 @@ int enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, 
         // wave ends only 0.34 ms after the first (C3), and small items cost more than that in ramps.
         int chunk_samples = 32;
         if ((p->samples + chunk_samples - 1) / chunk_samples > 64) chunk_samples = (p->samples + 63) / 64;
-        if (const char *k = getenv("RT_POOL_CHUNK")) // developer knob
+#ifdef RT_DEVELOPER_KNOBS // changes the summation order: never in the product build
+        if (const char *k = getenv("RT_POOL_CHUNK"))
             if (atoi(k) > 0) chunk_samples = atoi(k);
+#endif
         if (chunk_samples > p->samples) chunk_samples = p->samples;
         // sample batches (cancel polling) are cut on chunk boundaries, so batching changes nothing either
         batch = (batch + chunk_samples - 1) / chunk_samples * chunk_samples;
@@ -375,18 +305,9 @@ int enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, 
     s->last_stream = stream;
     s->has_stats = true;
     s->last_launches = (win.index == 0 ? 0 : s->last_launches) + launches;
-    // primary rays traced = owned pixels x samples
-    uint64_t owned = 0;
-    for (int r = 0; r < p->height; ++r)
-        if (a.strip_count <= 1 || (r / a.strip_rows) % a.strip_count == a.strip_index) ++owned;
-    const uint64_t traced = owned * (uint64_t)(windowed ? win.width : p->width) * (uint64_t)p->samples;
-    s->last_samples = (win.index == 0 ? 0 : s->last_samples) + traced;
-    if (p->scale > 1) // preview: one traced pixel per block
-        s->last_samples = (uint64_t)(a.cover_w / a.step_x) * (uint64_t)(a.cover_h / a.step_y) * (uint64_t)p->samples;
     return RT_OK;
 }
-
-} // namespace
+using rtapi::enqueue_render;
 
 extern "C" {
 
@@ -463,11 +384,19 @@ void rt_scene_destroy(RtScene *s) {
     delete s;
 }
 
-int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
-    if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "out is NULL");
-    *out = nullptr;
+int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) { return rt_scene_create_ex(d, device, nullptr, out); }
+
+namespace {
+int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options, RtScene **out) {
     int rc = validate_desc(d);
     if (rc != RT_OK) return rc;
+    RtSceneOptions opt;
+    memset(&opt, 0, sizeof opt);
+    if (options) opt = *options;
+    if (opt.closest_hit < RT_HIT_AUTO || opt.closest_hit > RT_HIT_BVH) return fail(RT_ERR_INVALID_ARGUMENT, "unknown closest_hit option");
+    if (opt.kernel < RT_KERNEL_POOL || opt.kernel > RT_KERNEL_V1) return fail(RT_ERR_INVALID_ARGUMENT, "unknown kernel option");
+    for (int32_t r : opt._reserved)
+        if (r != 0) return fail(RT_ERR_INVALID_ARGUMENT, "reserved option fields must be 0");
     int n_dev = rt_device_count();
     if (n_dev <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device is visible to this process");
     if (device < 0 || device >= n_dev) return fail(RT_ERR_INVALID_ARGUMENT, "device index out of range");
@@ -566,9 +495,10 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     // They cross at a few dozen primitives (clown.yml, 23 spheres, is still linear).
     const int kBvhThreshold = 48;
     s->use_bvh = d->n_primitives > kBvhThreshold;
-    if (const char *k = getenv("RT_BVH")) s->use_bvh = atoi(k) != 0 && d->n_primitives > 0; // developer knob
-    // (the linear-loop variants keep the whole primitive table in LDS: forcing them onto a scene of more than
-    // ~600 primitives exceeds a workgroup's LDS and the launch fails with RT_ERR_HIP)
+    if (opt.closest_hit != RT_HIT_AUTO) s->use_bvh = opt.closest_hit == RT_HIT_BVH && d->n_primitives > 0;
+    // the linear-loop variants keep the whole primitive table in LDS
+    if (!s->use_bvh && (size_t)d->n_primitives * sizeof(rtdev::Prim) > 120 * 1024)
+        return fail(RT_ERR_UNSUPPORTED, "RT_HIT_LINEAR: the primitive table does not fit in LDS");
     if (s->use_bvh) {
         rtdev::BvhBuild bvh = rtdev::build_bvh(d->primitives, d->n_primitives);
         if ((rc = upload(s->bvh_nodes, bvh.nodes)) != RT_OK) return rc;
@@ -593,16 +523,20 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
         s->bg.top[k] = d->background.top[k];
         s->bg.bottom[k] = d->background.bottom[k];
     }
-    if (const char *k = getenv("RT_TRACE_KERNEL")) s->use_v1 = strcmp(k, "v1") == 0;
+    s->use_v1 = opt.kernel == RT_KERNEL_V1;
     RT_HIP(hipDeviceGetAttribute(&s->num_cus, hipDeviceAttributeMultiprocessorCount, device));
     s->bvh_nodes_in_lds = s->use_bvh && (size_t)s->n_bvh_nodes * sizeof(rtdev::BvhNode) <= 32 * 1024;
-    if (const char *k = getenv("RT_BVH_LDS")) s->bvh_nodes_in_lds = s->bvh_nodes_in_lds && atoi(k) != 0; // developer knob
+#ifdef RT_DEVELOPER_KNOBS
+    if (const char *k = getenv("RT_BVH_LDS")) s->bvh_nodes_in_lds = s->bvh_nodes_in_lds && atoi(k) != 0;
+#endif
     // dynamic LDS of the variant: the BVH node array, or the primitive table of the linear-loop variants
     const size_t dyn_lds = s->use_bvh ? (s->bvh_nodes_in_lds ? (size_t)s->n_bvh_nodes * sizeof(rtdev::BvhNode) : 0)
                                       : (size_t)s->n_prims * sizeof(rtdev::Prim) + (s->textured ? (size_t)s->n_textures * sizeof(rtdev::Texture) : 0);
     s->pool_blocks_per_cu = rtdev_pool_blocks_per_cu(s->prims_class, s->textured, s->specular, s->use_bvh, dyn_lds);
-    if (const char *k = getenv("RT_POOL_BLOCKS_PER_CU")) // developer knob for occupancy experiments
+#ifdef RT_DEVELOPER_KNOBS // occupancy experiments
+    if (const char *k = getenv("RT_POOL_BLOCKS_PER_CU"))
         if (atoi(k) > 0) s->pool_blocks_per_cu = atoi(k);
+#endif
     RT_HIP(s->segments.alloc(16)); // [0] = path segments; [1..] = region cycles of a -DRT_PROFILE_REGIONS build
     RT_HIP(hipMemset(s->segments.ptr, 0, 16 * sizeof(unsigned long long)));
     RT_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
@@ -613,6 +547,19 @@ int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) {
     guard.s = nullptr;
     *out = s;
     return RT_OK;
+}
+} // namespace
+
+int rt_scene_create_ex(const RtSceneDesc *d, int device, const RtSceneOptions *options, RtScene **out) {
+    if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    try { // nothing may unwind through the C ABI (std::vector / std::string / the BVH build allocate)
+        return scene_create(d, device, options, out);
+    } catch (const std::bad_alloc &) {
+        return fail(RT_ERR_OUT_OF_MEMORY, "host allocation failed while building the scene");
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_INVALID_ARGUMENT, std::string("scene build failed: ") + e.what());
+    }
 }
 
 int rt_render_frame_device(RtScene *s, const RtCamera *camera, const RtRenderParams *p, double *out_dev,
@@ -826,8 +773,9 @@ int rt_scene_last_stats(RtScene *s, RtRenderStats *out) {
     float ms_trace = 0.f, ms_resolve = 0.f;
     RT_HIP(hipEventElapsedTime(&ms_trace, s->ev_begin, s->ev_traced));
     RT_HIP(hipEventElapsedTime(&ms_resolve, s->ev_traced, s->ev_resolved));
-    unsigned long long segs = 0;
-    RT_HIP(hipMemcpy(&segs, s->segments.ptr, sizeof segs, hipMemcpyDeviceToHost));
+    unsigned long long counters[16]; // rt_device_types.h: RT_STAT_*
+    RT_HIP(hipMemcpy(counters, s->segments.ptr, sizeof counters, hipMemcpyDeviceToHost));
+    const unsigned long long segs = counters[rtdev::RT_STAT_SEGMENTS];
 #ifdef RT_PROFILE_REGIONS
     {
         unsigned long long c[16];
@@ -844,7 +792,7 @@ int rt_scene_last_stats(RtScene *s, RtRenderStats *out) {
                 (double)(c[12] - c[11]) * 1e-5, (double)(c[13] - c[11]) * 1e-5, (double)(c[14] - c[11]) * 1e-5);
     }
 #endif
-    out->samples = s->last_samples;
+    out->samples = counters[rtdev::RT_STAT_SAMPLES]; // counted on the device where a path is handed out
     out->segments = segs;
     out->kernel_ms = ms_trace;
     out->resolve_ms = ms_resolve;

@@ -81,6 +81,10 @@ struct Background {
     double top[3], bottom[3];
 };
 
+// Slots of the statistics buffer TraceArgs.segments[16]: [0] path segments, [1..14] region cycles
+// of a -DRT_PROFILE_REGIONS build, [15] primary rays started (counted where a path is handed out).
+enum { RT_STAT_SEGMENTS = 0, RT_STAT_SAMPLES = 15 };
+
 // Kernel argument block (passed by value -> kernarg segment, scalar loads).
 struct TraceArgs {
     const Prim *prims;

@@ -1,0 +1,161 @@
+// rt_multi.hip — one frame on several GPUs of ONE process (include/rt_abi.h:
+// rt_render_frame_multi, rt_render_frame_multi_device).
+//
+// The reference shards a frame over its rayon pool by tile inside one
+// `CpuRenderer::render` call (racer-tracer/src/renderer/cpu.rs:118-131).  Here
+// the shards are 8-row strips, strip j -> scenes[j % n] (interleaved: cheap sky
+// rows and expensive floor rows spread evenly), every device traces its strips
+// on its own stream at the same time, and the finished strips are collected
+//   * to HOST memory by each device itself (its own PCIe link, no hop through
+//     device 0), or
+//   * to device 0's HBM by peer copies over xGMI, enqueued on the SOURCE
+//     device's stream right behind its resolve pass.
+// One process owns every device here, so plain peer copies (SDMA engines over
+// the xGMI links) do the gather; RCCL's rendezvous buys nothing without a
+// second process.  The multi-process form of the same gather is
+// racer-tracer_amd/strips.py (torch.distributed, backend "nccl" = RCCL).
+//
+// Host code only.
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include "rt_scene.h"
+
+using rtapi::fail;
+
+namespace {
+
+struct Share {
+    RtScene *scene;
+    RtRenderParams params;
+    double *target; // where this device's resolve pass writes (a full-frame sized buffer; owned rows only)
+    bool in_place;  // target IS the output buffer: no copy
+};
+
+int render_multi(RtScene *const *scenes, int n, const RtCamera *camera, const RtRenderParams *p, int strip_rows,
+                 double *out, bool out_on_device) {
+    if (!scenes || n <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "no scenes");
+    for (int i = 0; i < n; ++i)
+        if (!scenes[i]) return fail(RT_ERR_INVALID_ARGUMENT, "scenes[" + std::to_string(i) + "] is NULL");
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j)
+            if (scenes[i] == scenes[j]) return fail(RT_ERR_INVALID_ARGUMENT, "the same RtScene is listed twice (create one per share)");
+    if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "out is NULL");
+    int rc = rtapi::check_params(camera, p);
+    if (rc != RT_OK) return rc;
+    if (p->strip_count > 1) return fail(RT_ERR_INVALID_ARGUMENT, "params->strip_* must be unset: the call assigns strips itself");
+    if (p->scale > 1) return fail(RT_ERR_INVALID_ARGUMENT, "the preview scale cannot be combined with strips");
+    if (strip_rows < 0) return fail(RT_ERR_INVALID_ARGUMENT, "strip_rows must not be negative");
+    if (strip_rows == 0) strip_rows = 8;
+
+    const size_t row_elems = (size_t)p->width * 3;
+    const size_t n_elems = row_elems * (size_t)p->height;
+    const int n_strips = (p->height + strip_rows - 1) / strip_rows;
+    const int dst_device = scenes[0]->device;
+
+    std::vector<Share> shares((size_t)n);
+    // 1. every device starts tracing before any copy is enqueued (a copy to pageable host memory
+    //    blocks the calling thread)
+    for (int i = 0; i < n; ++i) {
+        Share &sh = shares[(size_t)i];
+        sh.scene = scenes[i];
+        sh.params = *p;
+        if (n > 1) {
+            sh.params.strip_rows = strip_rows;
+            sh.params.strip_count = n;
+            sh.params.strip_index = i;
+        }
+        RT_HIP(hipSetDevice(sh.scene->device));
+        sh.in_place = out_on_device && sh.scene->device == dst_device;
+        if (sh.in_place) {
+            sh.target = out;
+        } else {
+            if (sh.scene->frame.count < n_elems) RT_HIP(sh.scene->frame.alloc(n_elems));
+            sh.target = sh.scene->frame.ptr;
+        }
+        rc = rtapi::enqueue_render(sh.scene, camera, &sh.params, sh.target, sh.scene->stream, 0, nullptr);
+        if (rc != RT_OK) {
+            for (int j = 0; j <= i; ++j) (void)hipStreamSynchronize(scenes[j]->stream);
+            return rc;
+        }
+    }
+    // 2. every device sends its own strips, behind its resolve pass on its own stream
+    bool registered = false;
+    if (!out_on_device && n > 1) // pinned for the duration of the call: the D2H copies of all devices then overlap
+        registered = hipHostRegister(out, n_elems * sizeof(double), hipHostRegisterPortable) == hipSuccess;
+    if (!registered) (void)hipGetLastError();
+    if (out_on_device && n > 1) {
+        for (int i = 0; i < n; ++i) {
+            const int dev = scenes[i]->device;
+            if (dev == dst_device) continue;
+            RT_HIP(hipSetDevice(dev));
+            int can = 0;
+            RT_HIP(hipDeviceCanAccessPeer(&can, dev, dst_device));
+            if (can) {
+                const hipError_t e = hipDeviceEnablePeerAccess(dst_device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                    return fail(RT_ERR_HIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+                (void)hipGetLastError();
+            } // without peer access hipMemcpyPeerAsync stages through the host by itself
+        }
+    }
+    int first_error = RT_OK;
+    for (int i = 0; i < n && first_error == RT_OK; ++i) {
+        const Share &sh = shares[(size_t)i];
+        if (sh.in_place) continue;
+        if (hipSetDevice(sh.scene->device) != hipSuccess) {
+            first_error = fail(RT_ERR_HIP, "hipSetDevice failed");
+            break;
+        }
+        for (int j = (n > 1 ? i : 0); j < n_strips; j += (n > 1 ? n : 1)) {
+            const int r0 = j * strip_rows;
+            const int rows = (r0 + strip_rows <= p->height ? strip_rows : p->height - r0) ;
+            const size_t off = (size_t)r0 * row_elems, bytes = (size_t)rows * row_elems * sizeof(double);
+            hipError_t e;
+            if (n == 1) { // one share: the whole frame in one copy
+                e = out_on_device ? hipMemcpyPeerAsync(out, dst_device, sh.target, sh.scene->device, n_elems * sizeof(double), sh.scene->stream)
+                                  : hipMemcpyAsync(out, sh.target, n_elems * sizeof(double), hipMemcpyDeviceToHost, sh.scene->stream);
+                j = n_strips;
+            } else if (out_on_device) {
+                e = hipMemcpyPeerAsync(out + off, dst_device, sh.target + off, sh.scene->device, bytes, sh.scene->stream);
+            } else {
+                e = hipMemcpyAsync(out + off, sh.target + off, bytes, hipMemcpyDeviceToHost, sh.scene->stream);
+            }
+            if (e != hipSuccess) {
+                first_error = fail(RT_ERR_HIP, std::string("strip copy: ") + hipGetErrorString(e));
+                break;
+            }
+        }
+    }
+    // 3. the frame is complete when every stream has drained
+    for (int i = 0; i < n; ++i) {
+        if (hipSetDevice(scenes[i]->device) != hipSuccess || hipStreamSynchronize(scenes[i]->stream) != hipSuccess)
+            if (first_error == RT_OK) first_error = fail(RT_ERR_HIP, "stream synchronisation failed on share " + std::to_string(i));
+    }
+    if (registered) (void)hipHostUnregister(out);
+    return first_error;
+}
+
+} // namespace
+
+extern "C" {
+
+int rt_render_frame_multi(RtScene *const *scenes, int n_scenes, const RtCamera *camera, const RtRenderParams *params,
+                          int strip_rows, double *out_rgb) {
+    try {
+        return render_multi(scenes, n_scenes, camera, params, strip_rows, out_rgb, false);
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_OUT_OF_MEMORY, std::string("rt_render_frame_multi: ") + e.what());
+    }
+}
+
+int rt_render_frame_multi_device(RtScene *const *scenes, int n_scenes, const RtCamera *camera,
+                                 const RtRenderParams *params, int strip_rows, double *out_rgb_device) {
+    try {
+        return render_multi(scenes, n_scenes, camera, params, strip_rows, out_rgb_device, true);
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_OUT_OF_MEMORY, std::string("rt_render_frame_multi_device: ") + e.what());
+    }
+}
+
+} // extern "C"

@@ -60,13 +60,23 @@ __device__ __forceinline__ d3 unit(d3 a) {
 // refinement the compiler's full f64 division uses, without its scaling and
 // fix-up instructions).  Used where the reference divides several values by
 // one denominator; results differ from true division by an ulp or two.
+// -DRT_EXACT_DIV (tests only, build/libracer_tracer_amd_exact.so, compiled -ffp-contract=off): the
+// reference's own operations instead — IEEE division (vec3.rs:279-301 multiplies by 1/x, sphere.rs:52
+// and xy_rect.rs:31 divide) and sqrt + three divisions for unit_vector (vec3.rs:79-85) — so that a
+// parity test can tell an arithmetic difference from a traversal defect.
 __device__ __forceinline__ double rcp_f64(double x) {
+#ifdef RT_EXACT_DIV
+    return 1.0 / x;
+#endif
     const double r0 = __builtin_amdgcn_rcp(x);
     double r = fma(r0, fma(-x, r0, 1.0), r0);
     r = fma(r, fma(-x, r, 1.0), r);
     return __builtin_isfinite(r) ? r : r0; // x = 0 or inf: keep the hardware's inf / 0 like a true division
 }
 __device__ __forceinline__ double rsqrt_f64(double x) {
+#ifdef RT_EXACT_DIV
+    return 1.0 / sqrt(x);
+#endif
     double y = __builtin_amdgcn_rsq(x);
     double g = x * y, h = 0.5 * y;
     double r = fma(-h, g, 0.5);
@@ -79,8 +89,19 @@ __device__ __forceinline__ double rsqrt_f64(double x) {
 // vec3.rs:79-85 unit_vector with one reciprocal square root instead of a
 // square root and three divisions
 __device__ __forceinline__ d3 unit_fast(d3 a) {
+#ifdef RT_EXACT_DIV
+    return unit(a);
+#endif
     double inv = rsqrt_f64(len2(a));
     return d3{a.x * inv, a.y * inv, a.z * inv};
+}
+// num / den where `inv` = 1/den was formed once per ray (the reference divides: xy_rect.rs:31, sphere.rs:52)
+__device__ __forceinline__ double div_by(double num, double den, double inv) {
+#ifdef RT_EXACT_DIV
+    return num / den;
+#else
+    return num * inv;
+#endif
 }
 __device__ __forceinline__ d3 rcp3(d3 a) { return d3{rcp_f64(a.x), rcp_f64(a.y), rcp_f64(a.z)}; }
 __device__ __forceinline__ double comp(d3 a, int axis) { return axis == 0 ? a.x : (axis == 1 ? a.y : a.z); }
@@ -178,7 +199,7 @@ __device__ __forceinline__ bool rect_t(int axis, double a0, double a1, double b0
                                        d3 o, d3 d, d3 inv_d, double t_min, double t_max, double &t_out) {
     int ia = axis == 0 ? 1 : 0;
     int ib = axis == 2 ? 1 : 2;
-    const double t = (k - comp(o, axis)) * comp(inv_d, axis); // xy_rect.rs:31 divides; inv_d = 1/d per ray
+    const double t = div_by(k - comp(o, axis), comp(d, axis), comp(inv_d, axis)); // xy_rect.rs:31 divides; inv_d = 1/d per ray
     if (EARLY_OUT) {
         if (t < t_min || t > t_max) return false;
         const double a = comp(o, ia) + t * comp(d, ia);
@@ -239,9 +260,9 @@ __device__ __forceinline__ bool prim_t(const Prim &P, d3 o, d3 d, d3 inv_d, doub
         double disc = half_b * half_b - a * c;
         if (disc < 0.0) return false;
         double sqrtd = sqrt(disc);
-        double root = (-half_b - sqrtd) * inv_a; // sphere.rs:52 divides by a
+        double root = div_by(-half_b - sqrtd, a, inv_a); // sphere.rs:52 divides by a
         if (root < t_min || t_max < root) {
-            root = (-half_b + sqrtd) * inv_a;
+            root = div_by(-half_b + sqrtd, a, inv_a);
             if (root < t_min || t_max < root) return false;
         }
         t_out = root;

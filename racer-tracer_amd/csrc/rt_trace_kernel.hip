@@ -3,7 +3,7 @@
 // (see DESIGN.md 4.2).  Kept as the simple, order-exact reference form of the
 // device path (per-pixel sums in the oracle's sample order) and for A/B
 // measurements against the pooled kernel of rt_trace_pool_kernel.hip, which is
-// the default.  Select with RtScene option / env RT_TRACE_KERNEL=v1.
+// the default.  Selected with RtSceneOptions.kernel = RT_KERNEL_V1 (rt_scene_create_ex).
 #include "rt_trace_common.h"
 
 namespace rtdev {
@@ -50,10 +50,11 @@ __global__ __launch_bounds__(256) void k_trace_f64(const TraceArgs A) {
     uint32_t seg = 0;
     double ray_time = 0.0; // ray.rs:26-28; scattered rays inherit it
     bool alive = false;
-    unsigned int n_segments = 0;
+    unsigned int n_segments = 0, n_started = 0;
 
     while (s < A.sample_end) {
         if (!alive) {
+            ++n_started;
             // cpu.rs:39-40 + camera.rs:326-337
             rng.sample = (uint32_t)s;
             u4 bc = rng.block(0, RT_RNG_CAMERA, 0);
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void k_trace_f64(const TraceArgs A) {
             if (best < 0) { // background_color.rs:27-33 / :45-48
                 d3 bgc = ld3(A.bg.top);
                 if (A.bg.kind == RT_BG_SKY) {
-                    double t = 0.5 * (d.y * rsqrt_f64(len2(d)) + 1.0);
+                    double t = 0.5 * (unit_fast(d).y + 1.0);
                     bgc = (1.0 - t) * ld3(A.bg.top) + t * ld3(A.bg.bottom);
                 }
                 contrib = T * bgc;
@@ -193,6 +194,10 @@ __global__ __launch_bounds__(256) void k_trace_f64(const TraceArgs A) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
     if (lane == 0 && total) atomicAdd(A.segments, total);
+    unsigned long long started = n_started; // primary rays (RtRenderStats.samples)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) started += __shfl_down(started, off, 64);
+    if (lane == 0 && started) atomicAdd(A.segments + RT_STAT_SAMPLES, started);
 }
 
 // vec3.rs:119-125 scale_sqrt over the owned rows: out = sqrt(accum / samples)

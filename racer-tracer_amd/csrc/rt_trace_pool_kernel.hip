@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
     }
     const int lane = threadIdx.x & 63;
     WaveLds<PRIMS == PRIMS_ANY, NBUF> &L = lds_all[threadIdx.x >> 6];
-    unsigned int n_segments = 0;
+    unsigned int n_segments = 0, n_started = 0;
 
     RT_REGION_DECL
     for (;;) {
@@ -424,6 +424,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
                     T = mk(1.0, 1.0, 1.0);
                     seg = 0;
                     alive = true;
+                    ++n_started;
                 }
             }
             RT_REGION(2); // hand-out + primary ray
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
                         const RT_CONSTANT TraceArgs *K = kernargs_here();
                         d3 bgc = ld3(K->bg.top);
                         if (K->bg.kind == RT_BG_SKY) {
-                            const double t = 0.5 * (d.y * rsqrt_f64(len2(d)) + 1.0);
+                            const double t = 0.5 * (unit_fast(d).y + 1.0);
                             bgc = (1.0 - t) * bgc + t * ld3(K->bg.bottom);
                         }
                         contrib = T * bgc;
@@ -617,6 +618,10 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) total_segments += __shfl_down(total_segments, off, 64);
     if (lane == 0 && total_segments) atomicAdd(A.segments, total_segments);
+    unsigned long long started = n_started; // primary rays (RtRenderStats.samples)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) started += __shfl_down(started, off, 64);
+    if (lane == 0 && started) atomicAdd(A.segments + RT_STAT_SAMPLES, started);
 }
 
 // vec3.rs:119-125 scale_sqrt over the owned rows: out = sqrt(sum over chunks / samples),

@@ -201,6 +201,7 @@ Args Args::parse(int argc, const char *const *argv) {
         else if (s == "--image-action") a.image_action = image_action_from_str(val());
         else if (s == "--seed") a.seed = std::strtoull(val().c_str(), nullptr, 0);
         else if (s == "--device") a.device = std::atoi(val().c_str());
+        else if (s == "--devices") a.devices = std::atoi(val().c_str());
         else if (s == "-h" || s == "--help") a.help = true;
         else throw TracerError::ArgumentParsingError("unknown argument " + s);
     }

@@ -61,6 +61,7 @@ struct Args { // config.rs:12-28
     // additive (the reference has no headless mode and no seed):
     uint64_t seed = 1;
     int device = 0;
+    int devices = 1; // --devices N: render the frame on devices device .. device+N-1 (rt_render_frame_multi)
     bool help = false;
 
     static Args parse(int argc, const char *const *argv);

@@ -3,7 +3,8 @@
 //     -c/--config <file.yml>   (default ./config.yml, env CONFIG)
 //     -s/--scene  <file.yml|sandbox|random>
 //     --image-action <png|none>
-// plus --seed and --device.  The reference opens a window and renders when R
+// plus --seed, --device and --devices N (the frame is sharded over N GPUs of this
+// process the way the reference shards it over its rayon pool, cpu.rs:118-131).  The reference opens a window and renders when R
 // is released (scene_controller/interactive.rs:83-86); this renders the final
 // image once and exits, which is what `--image-action png` is for.
 #include <chrono>
@@ -43,7 +44,7 @@ int main(int argc, char **argv) {
         return e.code();
     }
     if (args.help) {
-        printf("racer-tracer-amd [-c config.yml] [-s scene.yml|sandbox] [--image-action png|none] [--seed N] [--device N]\n");
+        printf("racer-tracer-amd [-c config.yml] [-s scene.yml|sandbox] [--image-action png|none] [--seed N] [--device N] [--devices N]\n");
         return 0;
     }
     RthSession *session = nullptr;
@@ -56,23 +57,48 @@ int main(int argc, char **argv) {
     }
     RtRenderParams params;
     rth_session_params(session, 0, &params);
-    RtScene *scene = nullptr;
-    rc = rt_scene_create(rth_session_scene(session), args.device, &scene);
-    if (rc != RT_OK) {
-        fprintf(stderr, "%s: %s\n", rt_strerror(rc), rt_last_error_message());
+    if (args.devices < 1) {
+        fprintf(stderr, "--devices must be at least 1\n");
         rth_session_close(session);
-        return rc;
+        return RT_ERR_ARGUMENT_PARSING;
+    }
+    std::vector<RtScene *> scenes;
+    auto destroy_scenes = [&] {
+        for (RtScene *s : scenes) rt_scene_destroy(s);
+    };
+    for (int k = 0; k < args.devices; ++k) { // one upload of the (tiny) scene per device
+        RtScene *scene = nullptr;
+        rc = rt_scene_create(rth_session_scene(session), args.device + k, &scene);
+        if (rc != RT_OK) {
+            fprintf(stderr, "%s: %s\n", rt_strerror(rc), rt_last_error_message());
+            destroy_scenes();
+            rth_session_close(session);
+            return rc;
+        }
+        scenes.push_back(scene);
     }
     ScreenBuffer sb{session, params.width, params.height, std::vector<double>((size_t)params.width * (size_t)params.height * 3, 0.0)};
     fprintf(stderr, "Rendering image...\n"); // interactive.rs:229
     auto t0 = std::chrono::steady_clock::now();
-    rc = rt_render(scene, rth_session_camera(session), &params, on_tile, &sb, nullptr);
+    if (scenes.size() == 1) {
+        rc = rt_render(scenes[0], rth_session_camera(session), &params, on_tile, &sb, nullptr);
+    } else { // the whole frame as ONE BufferUpdate (renderer/image.rs:56-62), strips gathered from all devices
+        std::vector<double> frame(sb.buffer.size());
+        rc = rt_render_frame_multi(scenes.data(), (int)scenes.size(), rth_session_camera(session), &params, 0, frame.data());
+        if (rc == RT_OK) on_tile(&sb, frame.data(), 0, 0, params.width, params.height);
+    }
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (rc != RT_OK) {
         fprintf(stderr, "%s: %s\n", rt_strerror(rc), rt_last_error_message());
     } else {
-        RtRenderStats st;
-        rt_scene_last_stats(scene, &st);
+        RtRenderStats st{};
+        for (RtScene *s : scenes) { // every device's share
+            RtRenderStats one;
+            rt_scene_last_stats(s, &one);
+            st.samples += one.samples;
+            st.segments += one.segments;
+            st.kernel_ms = one.kernel_ms > st.kernel_ms ? one.kernel_ms : st.kernel_ms;
+        }
         fprintf(stderr, "It took %.3f seconds to render the image. (%.1f Msamples/s, %.2f segments/sample, kernel %.1f ms)\n",
                 secs, (double)st.samples / secs / 1e6, st.samples ? (double)st.segments / (double)st.samples : 0.0, st.kernel_ms);
         if (rth_session_image_action(session) == RTH_IMAGE_ACTION_SAVE_PNG) { // main.rs:153-156
@@ -84,7 +110,7 @@ int main(int argc, char **argv) {
             else fprintf(stderr, "No output directory for saving pngs. Skipping.\n");
         }
     }
-    rt_scene_destroy(scene);
+    destroy_scenes();
     rth_session_close(session);
     return rc;
 }

@@ -39,3 +39,31 @@ def gpu(rt):
     n = rt.device_count()
     assert n > 0, "pytest -m gpu needs a visible HIP device (rt_device_count() == 0)"
     return n
+
+
+# ---- bench.py --gpus 2, self-launched, on ONE card ---------------------------------------------
+# A process that has initialised the GPU must not start other GPU programs carelessly on this pool, and
+# pytest's process initialises it with the first `gpu` fixture.  So the rehearsal of `python bench.py
+# --gpus 2` (the command the driver runs; bench.py spawns its two ranks itself) is started HERE, before
+# any test runs, and tests/test_bench_launch.py only collects its result.
+def pytest_sessionstart(session):
+    session.config._bench_rehearsal = None
+    if (session.config.getoption("-m") or "").strip() != "gpu":
+        return
+    import subprocess
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    log = open(os.path.join(out_dir, "bench_rehearsal_gpus2.stderr.log"), "w")
+    env = dict(os.environ, BENCH_REHEARSE_ON_ONE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--spp", "64", "--no-cpu-baseline"]
+    session.config._bench_rehearsal = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=log, env=env, text=True, cwd=ROOT)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    proc = getattr(session.config, "_bench_rehearsal", None)
+    if proc is not None and proc.poll() is None:  # the collecting test did not run (e.g. -x stopped earlier)
+        proc.kill()
+        proc.wait()

@@ -35,7 +35,7 @@ def test_python_prototypes_cover_the_headers(rt):
 
 
 def test_abi_version_and_strerror(rt):
-    assert rt.lib().rt_abi_version() == rt.abi.ABI_VERSION == 2
+    assert rt.lib().rt_abi_version() == rt.abi.ABI_VERSION == 3
     # error.rs:71-97 numbering
     for code, text in ((0, "Ok"), (4, "Unknown Material"), (7, "Cancel event"), (9, "Scene failed to load"),
                        (21, "Failed to open image"), (100, "No usable HIP device")):
@@ -46,7 +46,7 @@ def test_abi_version_and_strerror(rt):
 
 def test_struct_layouts_match_the_c_compiler(abi):
     structs = ["RtTexture", "RtImage", "RtPerlin", "RtMaterial", "RtPrimitive", "RtBackground", "RtSceneDesc",
-               "RtCamera", "RtRenderParams", "RtRenderStats"]
+               "RtCamera", "RtRenderParams", "RtRenderStats", "RtToneMap", "RtSceneOptions"]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rt_abi.h"', 'int main(void){']
     for s in structs:
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (s, s))
@@ -76,6 +76,42 @@ def test_headers_are_plain_c(abi):
         if h != "rt_rng.h":  # macros only: an empty translation unit is not pedantic C
             flags.insert(1, "-pedantic")
         subprocess.check_call(["gcc"] + flags + [os.path.join(INC, h)])
+
+
+def test_product_library_reads_no_environment_knob():
+    """Developer knobs (RT_DBG*, RT_POOL_CHUNK, ...) exist only under -DRT_DEVELOPER_KNOBS; the shipped
+    library must behave the same in every environment (chunk boundaries are part of the bit-exact contract).
+    The one getenv left is the reference CLI's own `CONFIG` variable (config.rs:17)."""
+    so = os.path.join(ROOT, "racer-tracer_amd", "lib", "libracer_tracer_amd.so")
+    strings = subprocess.check_output(["strings", so]).decode().split("\n")
+    knobs = [s for s in strings if re.fullmatch(r"RT_[A-Z0-9_%d]+", s)]
+    assert knobs == [], knobs
+    csrc = os.path.join(ROOT, "racer-tracer_amd", "csrc")
+    for f in os.listdir(csrc):
+        text = open(os.path.join(csrc, f)).read()
+        outside = re.sub(r"#ifdef RT_DEVELOPER_KNOBS.*?#endif", "", text, flags=re.S)
+        assert "getenv" not in outside, f
+
+
+def test_multi_device_entry_points_validate_before_touching_a_device(rt, abi):
+    """rt_render_frame_multi* (cpu.rs:118-131 over GPUs): argument errors are reported without a device."""
+    cam, p = abi.RtCamera(), abi.render_params(16, 16, 1)
+    out = (C.c_double * (16 * 16 * 3))()
+    assert rt.lib().rt_render_frame_multi(None, 0, C.byref(cam), C.byref(p), 0, out) == abi.RT_ERR_INVALID_ARGUMENT
+    handles = (C.c_void_p * 2)(None, None)
+    assert rt.lib().rt_render_frame_multi(handles, 2, C.byref(cam), C.byref(p), 0, out) == abi.RT_ERR_INVALID_ARGUMENT
+    assert b"NULL" in rt.lib().rt_last_error_message()
+
+
+def test_scene_options_are_validated(rt, abi):
+    import scenes_py as S
+    bundle, _, _ = S.cornell_box()
+    h = C.c_void_p()
+    bad = abi.RtSceneOptions(7, 0)
+    assert rt.lib().rt_scene_create_ex(C.byref(bundle.desc), 0, C.byref(bad), C.byref(h)) == abi.RT_ERR_INVALID_ARGUMENT
+    bad = abi.RtSceneOptions(0, 0)
+    bad._reserved[2] = 1
+    assert rt.lib().rt_scene_create_ex(C.byref(bundle.desc), 0, C.byref(bad), C.byref(h)) == abi.RT_ERR_INVALID_ARGUMENT
 
 
 def test_no_device_is_an_error_not_a_fallback(rt):

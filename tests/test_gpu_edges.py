@@ -252,8 +252,8 @@ def test_white_furnace_is_exactly_white(rt, gpu):
 
 
 @pytest.mark.parametrize("scene_fn", [S.three_balls, S.cornell_box, S.cornell_box_boxes])
-def test_v1_kernel_still_matches_the_oracle(rt, orc, gpu, scene_fn, monkeypatch):
-    """RT_TRACE_KERNEL=v1 selects the lane-per-pixel kernel, the second implementation
+def test_v1_kernel_still_matches_the_oracle(rt, orc, gpu, scene_fn):
+    """RtSceneOptions.kernel = RT_KERNEL_V1 selects the lane-per-pixel kernel, the second implementation
     of the same contract: it must agree with the oracle, and with the pooled kernel to rounding."""
     bundle, cam, _ = scene_fn()
     w, h, spp = 96, 54, 12
@@ -262,9 +262,7 @@ def test_v1_kernel_still_matches_the_oracle(rt, orc, gpu, scene_fn, monkeypatch)
     ref, ref_segs = orc.render(bundle.desc, camera, params, use_bvh=0)
     frames = {}
     for name in ("pool", "v1"):
-        if name == "v1":
-            monkeypatch.setenv("RT_TRACE_KERNEL", "v1")
-        scene = rt.Scene(bundle)
+        scene = rt.Scene(bundle, kernel=S.abi.RT_KERNEL_V1 if name == "v1" else S.abi.RT_KERNEL_POOL)
         try:
             frames[name] = scene.render_frame(camera, params)
             segs = scene.last_stats().segments

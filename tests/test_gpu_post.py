@@ -1,5 +1,6 @@
-"""Device-side post pass (tone map + RGBA8 packing) against the host
-implementation: the bytes SavePng would hash and encode must be identical."""
+"""Device-side post pass (tone map + RGBA8 packing) against the host implementation AND the oracle
+(oracle/post.c): the bytes SavePng would hash and encode must be identical."""
+import ctypes as C
 import importlib
 import os
 import sys
@@ -35,7 +36,7 @@ def tone_map_sessions(host, tmp_path_factory):
     return out
 
 
-def test_device_post_equals_host_post(rt, host, gpu, tmp_path_factory):
+def test_device_post_equals_host_post_and_oracle(rt, host, orc, gpu, tmp_path_factory):
     import torch
     if not torch.cuda.is_available():   # the device buffers of this test come from torch; the library itself needs none
         pytest.skip("torch sees no GPU (the library does): no way to allocate the device buffers for this test")
@@ -60,6 +61,13 @@ def test_device_post_equals_host_post(rt, host, gpu, tmp_path_factory):
             assert np.array_equal(np.isnan(got_mapped), np.isnan(want_mapped)), name
             assert np.array_equal(np.nan_to_num(got_mapped), np.nan_to_num(want_mapped)), name   # bit-equal floats
             assert np.array_equal(dev_rgba.cpu().numpy(), host.pack_rgba8(want_mapped)), name       # identical bytes
+            # ... and against the ORACLE's tone map + packing (oracle/post.c), not only the product's host code
+            otm = orc.OrcToneMap.from_buffer_copy(s.tone_map_desc)     # same layout as RtToneMap
+            oracle_mapped = np.empty_like(rgb)
+            orc.lib().orc_tone_map_apply(C.byref(otm), rgb.ctypes.data_as(C.POINTER(C.c_double)),
+                                         oracle_mapped.ctypes.data_as(C.POINTER(C.c_double)), n)
+            assert np.array_equal(np.nan_to_num(got_mapped), np.nan_to_num(oracle_mapped)), name
+            assert np.array_equal(dev_rgba.cpu().numpy(), orc.pack_rgba8(oracle_mapped)), name
     finally:
         scene.close()
 

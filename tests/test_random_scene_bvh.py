@@ -163,21 +163,13 @@ def same_frame(a, b):
     return d.max() < 1e-3 and float((d.max(axis=-1) > 1e-9).mean()) < 2e-3
 
 
-def render_gpu(rt, desc, cam, params, env=None):
-    old = {k: os.environ.get(k) for k in (env or {})}
-    os.environ.update(env or {})
+def render_gpu(rt, desc, cam, params, closest_hit=abi.RT_HIT_AUTO):
+    """closest_hit: RtSceneOptions.closest_hit (rt_scene_create_ex)."""
+    scene = rt.Scene(desc, closest_hit=closest_hit)
     try:
-        scene = rt.Scene(desc)
-        try:
-            return scene.render_frame(cam, params), scene.last_stats()
-        finally:
-            scene.close()
+        return scene.render_frame(cam, params), scene.last_stats()
     finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        scene.close()
 
 
 @pytest.mark.gpu
@@ -188,7 +180,7 @@ def test_gpu_random_scene_matches_oracle_and_linear_loop(rt, host, orc, gpu):
     cam = host.camera_new((0, 2, 10), (0, 0, 0), 20.0, 0.1, 10.0, p.width, p.height)
     ref, ref_segs = orc.render(s.desc, cam, p, use_bvh=1)
     bvh, st = render_gpu(rt, s, cam, p)                       # 485 primitives -> BVH variant
-    lin, st_lin = render_gpu(rt, s, cam, p, {"RT_BVH": "0"})  # same scene through the brute-force loop
+    lin, st_lin = render_gpu(rt, s, cam, p, abi.RT_HIT_LINEAR)  # same scene through the brute-force loop
     d = np.abs(s.tone_map(bvh) - s.tone_map(ref))
     assert d.max() < 1e-3 and float((d.max(axis=-1) > 1e-9).mean()) < 2e-3
     assert abs(int(st.segments) - ref_segs) <= 4
@@ -205,7 +197,7 @@ def test_gpu_bvh_with_wrapped_primitives(rt, orc, gpu):
     params = abi.render_params(w, h, spp)
     ref, ref_segs = orc.render(bundle.desc, camera, params, use_bvh=0)   # linear: the oracle's BVH mirrors RotateY's box bug
     bvh, st = render_gpu(rt, bundle, camera, params)
-    lin, _ = render_gpu(rt, bundle, camera, params, {"RT_BVH": "0"})
+    lin, _ = render_gpu(rt, bundle, camera, params, abi.RT_HIT_LINEAR)
     d = np.abs(bvh - ref)
     assert d.max() < 1e-3 and float((d.max(axis=-1) > 1e-9).mean()) < 2e-3
     assert abs(int(st.segments) - ref_segs) <= 4
@@ -219,6 +211,6 @@ def test_gpu_small_scene_forced_through_bvh(rt, orc, gpu):
         bundle, cam, _ = fn()
         camera = S.camera_for(cam, 64, 36)
         params = abi.render_params(64, 36, 8)
-        a, _ = render_gpu(rt, bundle, camera, params, {"RT_BVH": "0"})
-        b, _ = render_gpu(rt, bundle, camera, params, {"RT_BVH": "1"})
+        a, _ = render_gpu(rt, bundle, camera, params, abi.RT_HIT_LINEAR)
+        b, _ = render_gpu(rt, bundle, camera, params, abi.RT_HIT_BVH)
         assert same_frame(a, b), fn.__name__

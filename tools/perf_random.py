@@ -4,11 +4,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 rt = importlib.import_module("racer-tracer_amd"); host = importlib.import_module("racer-tracer_amd.host")
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-modes = sys.argv[2:] or ["1", "0"]
+modes = sys.argv[2:] or ["bvh", "linear"]
 s = host.Session(os.path.join(ROOT, "scenes", "config_c2.yml"), scene="random")
 p = s.params; p.samples = spp
 for env in modes:
-    os.environ["RT_BVH"] = env
-    sc = rt.Scene(s); sc.render_frame(s.camera, p); st = sc.last_stats(); sc.close()
-    print("random 1080p %dspp RT_BVH=%s: kernel %.1f ms %.1f Msamples/s %.2f Gseg/s seg/sample %.2f"
+    sc = rt.Scene(s, closest_hit=rt.abi.RT_HIT_BVH if env == "bvh" else rt.abi.RT_HIT_LINEAR); sc.render_frame(s.camera, p); st = sc.last_stats(); sc.close()
+    print("random 1080p %dspp closest hit %s: kernel %.1f ms %.1f Msamples/s %.2f Gseg/s seg/sample %.2f"
           % (spp, env, st.kernel_ms, st.samples / st.kernel_ms / 1e3, st.segments / st.kernel_ms / 1e6, st.segments / st.samples), flush=True)
