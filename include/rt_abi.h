@@ -376,7 +376,9 @@ int rt_render_frame_rgba8(RtScene *scene, const RtCamera *camera, const RtRender
  *     RCCL, racer-tracer_amd/strips.py).  Synchronises before returning.
  * params->strip_* must be unset (the call sets them per device) and
  * params->scale <= 1.  The frame is bit-identical to rt_render_frame's for
- * every n_scenes (the RNG is addressed by the global pixel index).
+ * every n_scenes when strip_rows is a multiple of 8 (the RNG is addressed by the
+ * global pixel index and strips are then whole 8-row item tiles); other strip
+ * heights regroup the pixels that share a tile's sums and agree to rounding.
  * rt_scene_last_stats(scenes[i]) afterwards gives device i's share. */
 int rt_render_frame_multi(RtScene *const *scenes, int n_scenes, const RtCamera *camera,
                           const RtRenderParams *params, int strip_rows, double *out_rgb);

@@ -9,11 +9,18 @@
  * built or run here (no cargo/rustc; needs a window and a key press; is
  * unseeded), and its own tests hold only four Vec3 operator checks
  * (racer-tracer/src/vec3.rs:446-503).  Those are replayed in
- * tests/test_oracle_reference_vectors.py together with the only data the
- * reference itself produced: sky pixels of assets/three_balls.png and
- * assets/noise_and_textures.png (committed as values in tests/golden/).
- * Everything else on the path is PARITY UNPINNED by reference tests and is
- * held by hand-derived known answers and review.
+ * tests/test_oracle_reference_vectors.py together with everything the
+ * reference itself PRODUCED, its five 600x600 SavePng screenshots
+ * (assets/*.png, committed as values in tests/golden/reference_assets.json):
+ * sky pixels of three_balls.png / noise_and_textures.png exactly; 4x4 and 8x8
+ * block means of clown.png (< 0.001), three_balls.png (< 0.004) and of
+ * noise_and_textures.png outside its randomly seeded Perlin sphere (< 0.01);
+ * the position of both lights and of the background in emissive.png;
+ * layout, hue and the saturated light value of cornell_box.png.  What no
+ * reference output covers (Noise shading values, Box/RotateY/Translate,
+ * MovingSphere, Reinhard/Hable, the tile stream) is PARITY UNPINNED by the
+ * reference and held by hand-derived known answers and
+ * review.
  *
  * The POD scene/camera/param structs are the ones of include/rt_abi.h, so
  * oracle and device consume literally the same input bytes.

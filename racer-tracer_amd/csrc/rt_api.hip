@@ -222,7 +222,7 @@ int rtapi::enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderPara
         if (windowed) return fail(RT_ERR_UNSUPPORTED, "the v1 kernel has no column windows");
         if (s->accum.count < n) RT_HIP(s->accum.alloc(n));
         a.accum = s->accum.ptr;
-        RT_HIP(hipMemsetAsync(s->segments.ptr, 0, 16 * sizeof(unsigned long long), stream));
+        RT_HIP(hipMemsetAsync(s->segments.ptr, 0, rtdev::RT_STAT_SLOTS * sizeof(unsigned long long), stream));
         RT_HIP(hipEventRecord(s->ev_begin, stream));
         for (int b = 0; b < p->samples; b += batch) {
             if (cancel && *cancel) return RT_ERR_CANCEL_EVENT;
@@ -268,10 +268,10 @@ int rtapi::enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderPara
         a.partial = s->partial.ptr;
         a.chunk_samples = chunk_samples;
         if (win.index == 0) {
-            RT_HIP(hipMemsetAsync(s->segments.ptr, 0, 16 * sizeof(unsigned long long), stream));
+            RT_HIP(hipMemsetAsync(s->segments.ptr, 0, rtdev::RT_STAT_SLOTS * sizeof(unsigned long long), stream));
 #ifdef RT_PROFILE_REGIONS
-            RT_HIP(hipMemsetAsync(s->segments.ptr + 11, 0xff, sizeof(unsigned long long), stream)); // min slots
-            RT_HIP(hipMemsetAsync(s->segments.ptr + 13, 0xff, sizeof(unsigned long long), stream));
+            RT_HIP(hipMemsetAsync(s->segments.ptr + rtdev::RT_STAT_WALL + 0, 0xff, sizeof(unsigned long long), stream)); // min slots
+            RT_HIP(hipMemsetAsync(s->segments.ptr + rtdev::RT_STAT_WALL + 2, 0xff, sizeof(unsigned long long), stream));
 #endif
             RT_HIP(hipMemsetAsync(s->queue.ptr, 0, sizeof(unsigned int) * queue_slots, stream));
             RT_HIP(hipEventRecord(s->ev_begin, stream));
@@ -537,8 +537,8 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
     if (const char *k = getenv("RT_POOL_BLOCKS_PER_CU"))
         if (atoi(k) > 0) s->pool_blocks_per_cu = atoi(k);
 #endif
-    RT_HIP(s->segments.alloc(16)); // [0] = path segments; [1..] = region cycles of a -DRT_PROFILE_REGIONS build
-    RT_HIP(hipMemset(s->segments.ptr, 0, 16 * sizeof(unsigned long long)));
+    RT_HIP(s->segments.alloc(rtdev::RT_STAT_SLOTS)); // rt_device_types.h: RT_STAT_*
+    RT_HIP(hipMemset(s->segments.ptr, 0, rtdev::RT_STAT_SLOTS * sizeof(unsigned long long)));
     RT_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     RT_HIP(hipEventCreate(&s->ev_begin));
     RT_HIP(hipEventCreate(&s->ev_traced));
@@ -773,23 +773,40 @@ int rt_scene_last_stats(RtScene *s, RtRenderStats *out) {
     float ms_trace = 0.f, ms_resolve = 0.f;
     RT_HIP(hipEventElapsedTime(&ms_trace, s->ev_begin, s->ev_traced));
     RT_HIP(hipEventElapsedTime(&ms_resolve, s->ev_traced, s->ev_resolved));
-    unsigned long long counters[16]; // rt_device_types.h: RT_STAT_*
+    unsigned long long counters[rtdev::RT_STAT_SLOTS]; // rt_device_types.h: RT_STAT_*
     RT_HIP(hipMemcpy(counters, s->segments.ptr, sizeof counters, hipMemcpyDeviceToHost));
     const unsigned long long segs = counters[rtdev::RT_STAT_SEGMENTS];
 #ifdef RT_PROFILE_REGIONS
     {
-        unsigned long long c[16];
-        RT_HIP(hipMemcpy(c, s->segments.ptr, sizeof c, hipMemcpyDeviceToHost));
-        static const char *names[10] = {"item setup", "batches", "hand-out + primary ray", "closest hit", "miss/hit/material",
-                                        "sampler", "scatter + accumulate", "item end", "-", "-"};
+        const unsigned long long *c = counters;
+        static const char *names[16] = {"item setup", "batches", "hand-out + primary ray", "closest hit", "miss / material",
+                                        "sampler", "scatter + accumulate", "item end", "hit record", "texture, step 1",
+                                        "Noise rounds", "-", "-", "-", "-", "-"};
         double total = 0;
-        for (int k = 0; k < 8; ++k) total += (double)c[1 + k];
-        for (int k = 0; k < 8; ++k)
-            fprintf(stderr, "region %-24s %6.2f %%  (%.3g wave-cycles)\n", names[k], 100.0 * (double)c[1 + k] / total, (double)c[1 + k]);
-        if (c[9]) fprintf(stderr, "noise lookups: %.3g wave-iterations with one, %.1f lanes each on average\n", (double)c[9], (double)c[10] / (double)c[9]);
+        for (int k = 0; k < 16; ++k) total += (double)c[rtdev::RT_STAT_REGIONS + k];
+        for (int k = 0; k < 11; ++k)
+            fprintf(stderr, "region %-24s %6.2f %%  (%.3g wave-cycles)\n", names[k], 100.0 * (double)c[rtdev::RT_STAT_REGIONS + k] / total,
+                    (double)c[rtdev::RT_STAT_REGIONS + k]);
+        if (c[rtdev::RT_STAT_NOISE])
+            fprintf(stderr, "region noise lookups: %.3g wave-iterations with one, %.1f lanes each on average\n", (double)c[rtdev::RT_STAT_NOISE],
+                    (double)c[rtdev::RT_STAT_NOISE + 1] / (double)c[rtdev::RT_STAT_NOISE]);
+        // lanes tracing per iteration: while the pool has paths to hand out / in the item's tail
+        for (int part = 0; part < 2; ++part) {
+            const unsigned long long *h = c + (part ? rtdev::RT_STAT_LANES_TAIL : rtdev::RT_STAT_LANES_BODY);
+            double iters = 0, lanes = 0;
+            for (int k = 0; k < 9; ++k) {
+                iters += (double)h[k];
+                lanes += (double)h[k] * (k == 0 ? 0.0 : 8.0 * k - 3.5); // bin centre
+            }
+            fprintf(stderr, "region lanes tracing, %s: %.4g iterations, mean %.1f lanes; bins 0|1-8|..|57-64:", part ? "item tail (pool dry)" : "pool not dry  ",
+                    iters, iters > 0 ? lanes / iters : 0.0);
+            for (int k = 0; k < 9; ++k) fprintf(stderr, " %.1f%%", iters > 0 ? 100.0 * (double)h[k] / iters : 0.0);
+            fprintf(stderr, "\n");
+        }
         // 100 MHz wall clock: when did the first/last wave start and end (last launch of the call)
-        fprintf(stderr, "waves: last start +%.3f ms, first end +%.3f ms, last end +%.3f ms after the first start\n",
-                (double)(c[12] - c[11]) * 1e-5, (double)(c[13] - c[11]) * 1e-5, (double)(c[14] - c[11]) * 1e-5);
+        const unsigned long long *w = c + rtdev::RT_STAT_WALL;
+        fprintf(stderr, "region waves: last start +%.3f ms, first end +%.3f ms, last end +%.3f ms after the first start\n",
+                (double)(w[1] - w[0]) * 1e-5, (double)(w[2] - w[0]) * 1e-5, (double)(w[3] - w[0]) * 1e-5);
     }
 #endif
     out->samples = counters[rtdev::RT_STAT_SAMPLES]; // counted on the device where a path is handed out

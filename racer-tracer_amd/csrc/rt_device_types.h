@@ -81,9 +81,21 @@ struct Background {
     double top[3], bottom[3];
 };
 
-// Slots of the statistics buffer TraceArgs.segments[16]: [0] path segments, [1..14] region cycles
-// of a -DRT_PROFILE_REGIONS build, [15] primary rays started (counted where a path is handed out).
-enum { RT_STAT_SEGMENTS = 0, RT_STAT_SAMPLES = 15 };
+// Slots of the statistics buffer TraceArgs.segments[RT_STAT_SLOTS]: path segments, primary rays started
+// (counted where a path is handed out), and — written by a -DRT_PROFILE_REGIONS build only — shader-clock
+// cycles per region of the path loop, wall-clock marks of the first/last wave, and two histograms of the
+// lanes tracing per iteration (bins of 8: 0, 1-8, ..., 57-64): while the item's pool still has paths to
+// hand out, and after it ran dry (the item's tail).
+enum {
+    RT_STAT_SEGMENTS = 0,
+    RT_STAT_SAMPLES = 1,
+    RT_STAT_REGIONS = 2,      // 16 regions
+    RT_STAT_WALL = 18,        // first start, last start, first end, last end
+    RT_STAT_LANES_BODY = 22,  // 9 bins
+    RT_STAT_LANES_TAIL = 31,  // 9 bins
+    RT_STAT_NOISE = 40,       // wave-iterations with a Noise lookup, lookups
+    RT_STAT_SLOTS = 42
+};
 
 // Kernel argument block (passed by value -> kernarg segment, scalar loads).
 struct TraceArgs {

@@ -529,6 +529,46 @@ __device__ __forceinline__ d3 texture_value_full(const TraceArgs &A, const Perli
     return ld3(T->color);
 }
 
+// Texture::value in two steps for the pooled kernel.  Step 1 (per lane, inside the divergent shading
+// code): everything except the Perlin turbulence of a Noise texture; for a Noise texture the lane only
+// notes WHICH one (`noise_tex`, after a Checkered parent has picked its side) and returns zeros.
+// Step 2 (whole wave, coop_noise_turbulence in rt_trace_pool_kernel.hip) evaluates the turbulence of all
+// noted lookups together, and noise_colour() finishes noise.rs:26-33.
+__device__ __forceinline__ d3 texture_value_deferred(const TraceArgs &A, const Texture *textures, int ti, double u, double v,
+                                                     d3 p, int &noise_tex) {
+    const Texture *T = &textures[ti];
+    if (T->kind == RT_TEX_CHECKERED) { // checkered.rs:32-42
+        const int sines = sin_sign(p.x * 10.0) * sin_sign(p.y * 10.0) * sin_sign(p.z * 10.0);
+        ti = sines < 0 ? T->tex_odd : T->tex_even;
+        T = &textures[ti];
+    }
+    const int kind = T->kind;
+    if (kind == RT_TEX_IMAGE) { // texture/image.rs:28-51
+        const Image img = A.images[T->image];
+        const double uu = clamp01(u);
+        const double vv = 1.0 - clamp01(v);
+        double i = uu * (double)img.width;
+        double j = vv * (double)img.height;
+        if (i >= (double)img.width) i = (double)img.width - 1.0;
+        if (j >= (double)img.height) j = (double)img.height - 1.0;
+        const uint32_t xi = (uint32_t)i, yj = (uint32_t)j; // saturating, NaN -> 0
+        const uchar4 px = reinterpret_cast<const uchar4 *>(img.rgba)[(size_t)yj * (size_t)img.width + xi];
+        const double s = 1.0 / 255.0;
+        return mk((double)px.x * s, (double)px.y * s, (double)px.z * s);
+    }
+    if (kind == RT_TEX_NOISE) {
+        noise_tex = ti;
+        return mk(0.0, 0.0, 0.0);
+    }
+    return ld3(T->color);
+}
+
+// noise.rs:26-33 once the turbulence is known: color * 0.5 * (1 + sin(scale * p.z + 10 * turb))
+__device__ __forceinline__ d3 noise_colour(const Texture &T, d3 p, double turb) {
+    const double f = 1.0 + sin_lean(T.scale * p.z + 10.0 * turb);
+    return (ld3(T.color) * 0.5) * f;
+}
+
 template <bool TEXTURED>
 __device__ __forceinline__ d3 texture_value(const TraceArgs &A, const Perlin *lds_perlin, const Texture *textures,
                                             const Material &M, double u, double v, d3 p) {

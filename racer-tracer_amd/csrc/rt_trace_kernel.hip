@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_trace_f64(const TraceArgs A) {
     unsigned long long total = n_segments;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
-    if (lane == 0 && total) atomicAdd(A.segments, total);
+    if (lane == 0 && total) atomicAdd(A.segments + RT_STAT_SEGMENTS, total);
     unsigned long long started = n_started; // primary rays (RtRenderStats.samples)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) started += __shfl_down(started, off, 64);

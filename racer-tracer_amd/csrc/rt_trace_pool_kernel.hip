@@ -57,36 +57,46 @@
 namespace rtdev {
 
 // -DRT_PROFILE_REGIONS: developer build that accumulates the shader-clock cycles each wave
-// spends per region of the path loop into A.segments[1..]; rt_scene_last_stats prints them
+// spends per region of the path loop into A.segments[RT_STAT_REGIONS..]; rt_scene_last_stats prints them
 // (tools/region_profile.sh).  Not part of the product build.
 #ifdef RT_PROFILE_REGIONS
+// rt_t_[0..15] region cycles, [16] the previous marker, [17..34] the two lane histograms, [35..36] noise counts
 #define RT_REGION_DECL                                                          \
-    __shared__ unsigned long long rt_t_all_[4][12];                             \
+    __shared__ unsigned long long rt_t_all_[4][40];                             \
     unsigned long long *rt_t_ = rt_t_all_[threadIdx.x >> 6];                    \
-    if ((threadIdx.x & 63) < 11) rt_t_[threadIdx.x & 63] = 0;                   \
-    if ((threadIdx.x & 63) == 11) rt_t_[11] = __builtin_readcyclecounter();   \
+    if ((threadIdx.x & 63) < 40) rt_t_[threadIdx.x & 63] = 0;                   \
+    if ((threadIdx.x & 63) == 16) rt_t_[16] = __builtin_readcyclecounter();   \
     const unsigned long long rt_wave_start_ = wall_clock64();
 // usable inside divergent code: the first ACTIVE lane books the time since the previous marker
 #define RT_REGION(k)                                                            \
     do {                                                                        \
         if (lane_rank(__ballot(1)) == 0) {                                      \
             const unsigned long long now_ = __builtin_readcyclecounter();       \
-            rt_t_[k] += now_ - rt_t_[11];                                       \
-            rt_t_[11] = now_;                                                   \
+            rt_t_[k] += now_ - rt_t_[16];                                       \
+            rt_t_[16] = now_;                                                   \
         }                                                                       \
     } while (0)
+/* lanes tracing this iteration (wave-uniform n), booked while the pool has entries / in the item's tail */ \
+#define RT_LANES(n, tail)                                                       \
+    do {                                                                        \
+        const int n_ = (n); /* the ballot needs every lane */                   \
+        if (lane == 0) rt_t_[17 + ((tail) ? 9 : 0) + (n_ + 7) / 8] += 1;        \
+    } while (0)
 #define RT_REGION_FLUSH                                                         \
-    if (lane < 10) atomicAdd(A.segments + 1 + lane, rt_t_[lane]);               \
+    if (lane < 16) atomicAdd(A.segments + RT_STAT_REGIONS + lane, rt_t_[lane]); \
+    if (lane < 18) atomicAdd(A.segments + RT_STAT_LANES_BODY + lane, rt_t_[17 + lane]); \
+    if (lane < 2) atomicAdd(A.segments + RT_STAT_NOISE + lane, rt_t_[35 + lane]); \
     if (lane == 0) { /* wall clock (100 MHz) of the first/last wave start and end */ \
         const unsigned long long end_ = wall_clock64();                         \
-        atomicMin(A.segments + 11, rt_wave_start_);                             \
-        atomicMax(A.segments + 12, rt_wave_start_);                             \
-        atomicMin(A.segments + 13, end_);                                       \
-        atomicMax(A.segments + 14, end_);                                       \
+        atomicMin(A.segments + RT_STAT_WALL + 0, rt_wave_start_);               \
+        atomicMax(A.segments + RT_STAT_WALL + 1, rt_wave_start_);               \
+        atomicMin(A.segments + RT_STAT_WALL + 2, end_);                         \
+        atomicMax(A.segments + RT_STAT_WALL + 3, end_);                         \
     }
 #else
 #define RT_REGION_DECL
 #define RT_REGION(k)
+#define RT_LANES(n, tail)
 #define RT_REGION_FLUSH
 #endif
 
@@ -94,9 +104,20 @@ __device__ __forceinline__ int lane_rank(uint64_t mask) { // set bits of `mask` 
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// Request slots of the wave-cooperative Perlin turbulence (coop_noise_turbulence): eight lookups per
+// round, eight lanes each.
+struct NoiseSlots {
+    double p[8][3];    // hit point of the lookup
+    int depth[8];      // its texture's octave count (noise.rs:28)
+    int perlin[8];     // ... and gradient table
+    double term[8][8]; // 0.5^o * noise(2^o * p) of the round's octaves, summed in order by the requester
+};
+struct NoNoiseSlots {};
+
 // Per-wave scratch in LDS.  HAS_TIME: the scene has MovingSpheres (PRIMS_ANY variants).
 // NBUF: batches of camera samples kept (2, or 1 for the BVH variants, whose node array wants the LDS).
-template <bool HAS_TIME, int NBUF> struct WaveLds {
+template <bool HAS_TIME, int NBUF, bool TEXTURED> struct WaveLds {
+    typename std::conditional<TEXTURED, NoiseSlots, NoNoiseSlots>::type noise;
     // per pixel of the item's tile: upper_left_corner + u * horizontal with the pixel's ONE
     // horizontal jitter u = (px + ju) / (W - 1) (cpu.rs:35-36, camera.rs:331)
     double base[64][3];
@@ -222,6 +243,58 @@ __device__ __forceinline__ void coop_random_in_unit_disk(bool need, uint32_t pix
     }
 }
 
+// SHADING SORTED BY COST: the one expensive texture.  A marble lookup (noise.rs:26-33, :98-109) is seven
+// octaves of eight gradient dots, ~900 VALU instructions, and in a wave of 64 paths it is typically wanted by
+// a handful of lanes at a time (noise_and_textures: <= 4 lanes in 60 % of the iterations that have one), so
+// evaluated where the hit is shaded it runs at ~6 % lane use.  Octaves are independent until they are
+// summed, so the wave evaluates them side by side instead: lanes note their lookup during shading
+// (texture_value_deferred), then — all 64 lanes, wave-uniform control flow — eight lookups per round take
+// eight lanes each, lane o of a group computes octave o (0.5^o * noise(2^o p), both scalings exact), and
+// the requester adds the terms in octave order like the reference's loop.  One round costs about what ONE
+// octave costs.  Every lookup goes through this code, so a value never depends on which lanes sat next to it.
+// Returns turb(p, depth) (noise.rs:98-109) to the lanes with `need`; must be called by the whole wave.
+__device__ __forceinline__ double coop_noise_turbulence(bool need, d3 p, int depth, int perlin, const TraceArgs &A,
+                                                        const Perlin *lds_perlin, int lane, NoiseSlots &S) {
+    double turb = 0.0;
+    const uint64_t pending = __ballot(need);
+    const int n = __popcll(pending);
+    const int rank = lane_rank(pending);
+    const int j = lane >> 3, o8 = lane & 7; // this lane works on request j of the round, octave o8 (+ 8 per pass)
+    for (int r0 = 0; r0 < n; r0 += 8) {
+        const bool mine = need && rank >= r0 && rank < r0 + 8;
+        const int slot = rank - r0;
+        if (mine) {
+            S.p[slot][0] = p.x;
+            S.p[slot][1] = p.y;
+            S.p[slot][2] = p.z;
+            S.depth[slot] = depth;
+            S.perlin[slot] = perlin;
+        }
+        const bool serving = r0 + j < n;
+        const int dj = serving ? S.depth[j] : 0;
+        double accum = 0.0; // noise.rs:99
+        for (int ob = 0; __ballot(serving && ob < dj) != 0; ob += 8) { // one pass unless a texture has more than 8 octaves
+            const int o = ob + o8;
+            double term = 0.0;
+            if (serving && o < dj) {
+                // noise.rs:103-106: temp_p doubles and weight halves per octave — powers of two, exact
+                const d3 q = mk(__builtin_ldexp(S.p[j][0], o), __builtin_ldexp(S.p[j][1], o), __builtin_ldexp(S.p[j][2], o));
+                const int pi = S.perlin[j];
+                const double nz = (lds_perlin != nullptr && pi == 0) ? perlin_noise<true>(*lds_perlin, q)
+                                                                     : perlin_noise<false>(A.perlins[pi], q);
+                term = __builtin_ldexp(nz, -o);
+            }
+            S.term[j][o8] = term;
+            if (mine) { // accum += weight * noise(temp_p), in octave order (absent octaves are +0.0)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) accum += S.term[slot][k];
+            }
+        }
+        if (mine) turb = fabs(accum); // noise.rs:108
+    }
+    return turb;
+}
+
 // BVH: closest hit through the skip-link hierarchy instead of the linear loop
 // (instantiated for PRIMS_ANY only; chosen for scenes with many primitives).
 template <int PRIMS, bool TEXTURED, bool SPECULAR, bool BVH>
@@ -230,7 +303,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
     // boundary; the BVH variants keep one (their node array wants the LDS: three resident blocks
     // instead of two on the `random` scene) and a hand-out stops at the end of its batch.
     constexpr int NBUF = BVH ? 1 : 2;
-    __shared__ WaveLds<PRIMS == PRIMS_ANY, NBUF> lds_all[4];
+    __shared__ WaveLds<PRIMS == PRIMS_ANY, NBUF, TEXTURED> lds_all[4];
     // The gradients of the first Perlin table (6 KB) are staged in LDS once per block when the
     // permutation tables are the identity (always, in the reference: noise.rs:121-130): the 56
     // random gradient fetches of a marble lookup then hit LDS instead of the vector memory
@@ -285,7 +358,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
-    WaveLds<PRIMS == PRIMS_ANY, NBUF> &L = lds_all[threadIdx.x >> 6];
+    WaveLds<PRIMS == PRIMS_ANY, NBUF, TEXTURED> &L = lds_all[threadIdx.x >> 6];
     unsigned int n_segments = 0, n_started = 0;
 
     RT_REGION_DECL
@@ -318,7 +391,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
             PathRng prng{my_pixel, RT_RNG_SAMPLE_PIXEL, A.seed_lo, A.seed_hi};
             u4 bj = prng.block(0, RT_RNG_PIXEL, 0);
             const RT_CONSTANT TraceArgs *K = kernargs_here();
-            const double u = ((double)my_px + u53(bj.a, bj.b)) * K->inv_width_m1; // cpu.rs:35-36
+            const double u = div_by((double)my_px + u53(bj.a, bj.b), (double)(A.width - 1), K->inv_width_m1); // cpu.rs:35-36
             const d3 base = ld3(K->cam.ulc) + u * ld3(K->cam.horizontal);         // camera.rs:331, first two terms
             L.base[lane][0] = base.x;
             L.base[lane][1] = base.y;
@@ -365,7 +438,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
             if (in_pool) entry_of(w, pix_b, py_b, pixel_b, sample_b);
             const u4 bc = philox4x32(pixel_b, sample_b, RT_RNG_CAMERA, 0u, A.seed_lo, A.seed_hi);
             const int buf = (int)(b & (uint32_t)(NBUF - 1));
-            L.v[buf][lane] = ((double)py_b + u53(bc.a, bc.b)) * K->inv_height_m1; // cpu.rs:39-40
+            L.v[buf][lane] = div_by((double)py_b + u53(bc.a, bc.b), (double)(A.height - 1), K->inv_height_m1); // cpu.rs:39-40
             // camera.rs:335: the ray's time, second double of the same block (MovingSphere reads it)
             if (PRIMS == PRIMS_ANY) L.time[buf][lane] = K->cam.time_a + (K->cam.time_b - K->cam.time_a) * u53(bc.c, bc.d);
             // camera.rs:327: aperture 0 multiplies the disk by 0, so its draws are dead and skipped
@@ -435,6 +508,8 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
             bool ended = false;
             bool scattered = false;  // the path got a new ray this iteration (depth check below)
             bool finish = false;     // Lambertian / Metal hit whose direction can be completed now
+            int noise_tex = -1;      // Noise texture this lane's hit wants (evaluated by the whole wave below)
+            RT_LANES(__popcll(__ballot(alive && !waiting)), next >= total);
             if (alive && !waiting) {
                 if (A.max_depth <= 0) { // renderer.rs:48-55 with max_depth 0
                     contrib = T;
@@ -485,12 +560,13 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
                         const Material &M = P.mat;
                         const Hit h = prim_hit_record<PRIMS, TEXTURED>(P, o, d, ray_time, best_t, best_aux, M.needs_uv != 0);
                         const int kind = M.kind;
+                        RT_REGION(8); // hit record
 #ifdef RT_PROFILE_REGIONS
                         { // how many lanes of an iteration look up a Noise texture together?
                             const int n_noise = __popcll(__ballot(TEXTURED && M.tex_kind == RT_TEX_NOISE));
                             if (n_noise > 0 && lane_rank(__ballot(1)) == 0) {
-                                rt_t_[8] += 1;
-                                rt_t_[9] += (unsigned long long)n_noise;
+                                rt_t_[35] += 1;
+                                rt_t_[36] += (unsigned long long)n_noise;
                             }
                         }
 #endif
@@ -498,12 +574,14 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
                         // one copy of the texture code, shared by the lanes of all three
                         d3 tex = mk(0.0, 0.0, 0.0);
                         if (kind != RT_MAT_DIELECTRIC) {
-                            if (BVH) tex = texture_value<TEXTURED>(A, lds_perlin, A.textures, M, h.u, h.v, h.point);
-                            else tex = texture_value<TEXTURED>(A, lds_perlin, lds_textures, M, h.u, h.v, h.point);
+                            if (!TEXTURED || M.tex_kind == RT_TEX_SOLID_COLOR) tex = ld3(M.color); // solid_color.rs:24-28
+                            else tex = texture_value_deferred(A, BVH ? A.textures : lds_textures, M.texture, h.u, h.v, h.point, noise_tex);
                         }
+                        RT_REGION(9); // texture, step 1
                         if (kind == RT_MAT_DIFFUSE_LIGHT) { // diffuse_light.rs:25-37
                             contrib = T * tex;
                             ended = true;
+                            if (TEXTURED) hit_point = h.point; // a Noise light is finished below
                         } else if (kind == RT_MAT_LAMBERTIAN) { // lambertian.rs:26-38 (direction below)
                             albedo = tex;
                             hit_point = h.point;
@@ -556,7 +634,21 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
             // settle ~90 % and a third costs more than the idle lanes it saves; where an iteration
             // is expensive (textures, glass) or requests are few, up to four rounds pay: the loop
             // stops as soon as nothing is pending (measured: C2 +1.4 %, C4 +2.7 %, C3 -9 % with 3).
-            RT_REGION(4); // miss / hit record / material
+            RT_REGION(4); // miss / material
+            if constexpr (TEXTURED) { // the Noise lookups of this iteration, by the whole wave (all 64 lanes arrive here)
+                const bool lookup = noise_tex >= 0;
+                if (__ballot(lookup) != 0) {
+                    const Texture *tt = BVH ? A.textures : lds_textures;
+                    const double turb = coop_noise_turbulence(lookup, hit_point, lookup ? tt[noise_tex].depth : 0,
+                                                              lookup ? tt[noise_tex].perlin : 0, A, lds_perlin, lane, L.noise);
+                    if (lookup) {
+                        const d3 tex = noise_colour(tt[noise_tex], hit_point, turb);
+                        if (ended) contrib = T * tex; // DiffuseLight: the only material that ends on a textured hit
+                        else albedo = tex;            // Lambertian / Metal attenuation
+                    }
+                }
+            }
+            RT_REGION(10); // Noise rounds
             d3 sph = mk(0.0, 0.0, 0.0);
             if (coop_random_in_unit_sphere(waiting, rng.pixel, rng.sample, seg, cand_base, A.seed_lo, A.seed_hi, lane,
                                            L.req, (TEXTURED || SPECULAR) ? 4 : 2, sph)) {
@@ -617,7 +709,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
     unsigned long long total_segments = n_segments; // one atomic per wave for the statistic
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) total_segments += __shfl_down(total_segments, off, 64);
-    if (lane == 0 && total_segments) atomicAdd(A.segments, total_segments);
+    if (lane == 0 && total_segments) atomicAdd(A.segments + RT_STAT_SEGMENTS, total_segments);
     unsigned long long started = n_started; // primary rays (RtRenderStats.samples)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) started += __shfl_down(started, off, 64);

@@ -10,8 +10,15 @@ PIL (nothing from the reference is executed) and stores
     sky pixels do not depend on the random jitter beyond rounding, so they pin
     camera basis, pixel->(u,v) mapping, Sky, sqrt gamma, tone map None and the
     truncating x255 quantisation;
-  * 4x4 block means of three_balls.png / cornell_box.png /
-    noise_and_textures.png (weak statistical goldens, SURVEY.md section 4);
+  * 4x4 and 8x8 block means of three_balls.png / cornell_box.png /
+    noise_and_textures.png / clown.png / emissive.png (statistical goldens: a block is
+    150x150 or 75x75 pixels of a 200-spp image, so its mean carries next to no Monte Carlo
+    noise; clown.yml and three_balls.yml are fully deterministic scenes, noise_and_textures.yml
+    outside its randomly seeded Perlin sphere too);
+  * for emissive.png, whose lights are brighter than the shipped emissive.yml's (the screenshot
+    predates the scene file, like cornell_box.png) and whose every diffuse surface is a randomly
+    seeded Noise texture: where its two lights ARE — per-row and per-column counts of saturated
+    pixels — and a grid of pure-background pixels;
   * a 16x8 grid of texels of resources/images/earthmap.jpg as decoded by PIL
     (libjpeg-turbo), to pin the library's own baseline-JPEG decoder.
 
@@ -40,10 +47,26 @@ def main():
             for x in (0, 150, 300, 450, 599):
                 pts.append({"x": x, "y": y, "rgba": [int(v) for v in img[y, x]]})
         out["sky_pixels"][name] = pts
-    for name in ("three_balls", "cornell_box", "noise_and_textures"):
+    out["block_means_8x8"] = {}
+    for name in ("three_balls", "cornell_box", "noise_and_textures", "clown", "emissive"):
         img = np.array(Image.open(os.path.join(REF, "assets", name + ".png")).convert("RGB")).astype(np.float64) / 255.0
+        assert img.shape == (600, 600, 3)
         bm = img.reshape(4, 150, 4, 150, 3).mean(axis=(1, 3))
         out["block_means"][name] = np.round(bm, 5).tolist()
+        bm8 = img.reshape(8, 75, 8, 75, 3).mean(axis=(1, 3))
+        out["block_means_8x8"][name] = np.round(bm8, 5).tolist()
+    em = np.array(Image.open(os.path.join(REF, "assets", "emissive.png")).convert("RGB")).astype(int)
+    lit = (em >= 250).all(axis=-1)            # both lights saturate in the screenshot: (255, 255, 254) / (255, 255, 255)
+    black = (em == 0).all(axis=-1)
+    grid = [(x, y) for y in range(12, 600, 25) for x in range(12, 600, 25)]
+    out["emissive_layout"] = {
+        "lit_threshold": 250,
+        "lit_pixels": int(lit.sum()),
+        "lit_row_counts": lit.sum(axis=1).tolist(),
+        "lit_col_counts": lit.sum(axis=0).tolist(),
+        # grid points whose whole 9x9 neighbourhood is background in the screenshot
+        "black_grid": [[x, y] for x, y in grid if black[y - 4:y + 5, x - 4:x + 5].all()],
+    }
     earth = np.array(Image.open(os.path.join(REF, "resources", "images", "earthmap.jpg")).convert("RGBA"))
     out["earthmap_texels"] = {"width": int(earth.shape[1]), "height": int(earth.shape[0]), "step": 64,
                               "offset": 17,

@@ -186,7 +186,9 @@ def test_config5_share_at_full_spp(rt, orc, gpu):
         scene.close()
     own = band_rows(h, 8, 8, rank)
     assert stats.samples == int(own.sum()) * w * spp
-    assert (part[~own] == 0).all() and (part[own].max(axis=(1, 2)) > 0).all()
+    lit = np.zeros(h, dtype=bool)
+    lit[200:1960] = True                     # rows the open box covers at 16:9 (black background above and below)
+    assert (part[~own] == 0).all() and (part[own & lit].max(axis=(1, 2)) > 0).all()
     band = S.abi.render_params(w, h, spp, strip_rows=2, strip_count=h // 2, strip_index=524)   # rows 1048, 1049 (strip 131 = rank 3)
     ref, _ = orc.render(bundle.desc, camera, band)
     rows = band_rows(h, 2, h // 2, 524)
@@ -209,9 +211,12 @@ def test_multi_device_call_on_one_card(rt, orc, gpu):
     scenes = [rt.Scene(bundle) for _ in range(3)]
     try:
         whole = scenes[0].render_frame(camera, params)
-        for n, strip_rows in ((1, 0), (2, 0), (3, 8), (3, 5)):
+        for n, strip_rows in ((1, 0), (2, 0), (3, 8), (2, 16), (3, 5)):
             got = rt.render_frame_multi(scenes[:n], camera, params, strip_rows)
-            assert np.array_equal(got, whole), (n, strip_rows)
+            if strip_rows % 8 == 0:   # strips made of whole 8-row item tiles: the very same sums
+                assert np.array_equal(got, whole), (n, strip_rows)
+            else:                     # other strip heights regroup pixels into other item tiles: equal to rounding
+                assert np.abs(got - whole).max() < 1e-12, (n, strip_rows)
             traced = sum(int(s.last_stats().samples) for s in scenes[:n])
             assert traced == w * h * spp, (n, strip_rows)
         ref, _ = orc.render(bundle.desc, camera, params, use_bvh=0)
