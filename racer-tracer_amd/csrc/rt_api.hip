@@ -430,20 +430,6 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
             q.rot_cos = 1.0 / (p.time_b - p.time_a);
         }
     }
-    std::vector<rtdev::Texture> textures((size_t)d->n_textures);
-    for (int i = 0; i < d->n_textures; ++i) {
-        const RtTexture &t = d->textures[i];
-        rtdev::Texture &q = textures[(size_t)i];
-        memset(&q, 0, sizeof q);
-        q.kind = t.kind;
-        q.tex_even = t.tex_even;
-        q.tex_odd = t.tex_odd;
-        q.image = t.image;
-        q.perlin = t.perlin;
-        q.depth = t.depth;
-        for (int k = 0; k < 3; ++k) q.color[k] = t.color[k];
-        q.scale = t.scale;
-    }
     std::vector<rtdev::Material> materials((size_t)d->n_materials);
     for (int i = 0; i < d->n_materials; ++i) {
         const RtMaterial &m = d->materials[i];
@@ -471,6 +457,25 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
         images[(size_t)i].rgba = s->image_pixels[(size_t)i];
         images[(size_t)i].width = d->images[i].width;
         images[(size_t)i].height = d->images[i].height;
+    }
+    std::vector<rtdev::Texture> textures((size_t)d->n_textures);
+    for (int i = 0; i < d->n_textures; ++i) {
+        const RtTexture &t = d->textures[i];
+        rtdev::Texture &q = textures[(size_t)i];
+        memset(&q, 0, sizeof q);
+        q.kind = t.kind;
+        q.tex_even = t.tex_even;
+        q.tex_odd = t.tex_odd;
+        q.image = t.image;
+        q.perlin = t.perlin;
+        q.depth = t.depth;
+        for (int k = 0; k < 3; ++k) q.color[k] = t.color[k];
+        q.scale = t.scale;
+        if (t.kind == RT_TEX_IMAGE) { // the device record of its image, embedded (rt_device_types.h)
+            q.img.rgba = images[(size_t)t.image].rgba;
+            q.img.width = images[(size_t)t.image].width;
+            q.img.height = images[(size_t)t.image].height;
+        }
     }
     std::vector<rtdev::Perlin> perlins((size_t)d->n_perlins);
     for (int i = 0; i < d->n_perlins; ++i) {

@@ -46,7 +46,13 @@ struct alignas(16) Texture { // 64 B
     int32_t tex_even, tex_odd;
     int32_t image, perlin, depth;
     int32_t _pad[2];
-    double color[3];
+    union {
+        double color[3]; // SolidColor / Noise
+        struct {         // Image: a copy of images[image], so that a lookup is ONE dependent load (the texel), not
+            const uint8_t *rgba; // texture -> image record -> texel (the texture table sits in LDS in the pooled kernel)
+            int32_t width, height;
+        } img;
+    };
     double scale;
 };
 static_assert(sizeof(Texture) == 64, "Texture must be 64 bytes");

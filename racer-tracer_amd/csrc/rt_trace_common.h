@@ -544,15 +544,15 @@ __device__ __forceinline__ d3 texture_value_deferred(const TraceArgs &A, const T
     }
     const int kind = T->kind;
     if (kind == RT_TEX_IMAGE) { // texture/image.rs:28-51
-        const Image img = A.images[T->image];
+        const int width = T->img.width, height = T->img.height;
         const double uu = clamp01(u);
         const double vv = 1.0 - clamp01(v);
-        double i = uu * (double)img.width;
-        double j = vv * (double)img.height;
-        if (i >= (double)img.width) i = (double)img.width - 1.0;
-        if (j >= (double)img.height) j = (double)img.height - 1.0;
+        double i = uu * (double)width;
+        double j = vv * (double)height;
+        if (i >= (double)width) i = (double)width - 1.0;
+        if (j >= (double)height) j = (double)height - 1.0;
         const uint32_t xi = (uint32_t)i, yj = (uint32_t)j; // saturating, NaN -> 0
-        const uchar4 px = reinterpret_cast<const uchar4 *>(img.rgba)[(size_t)yj * (size_t)img.width + xi];
+        const uchar4 px = reinterpret_cast<const uchar4 *>(T->img.rgba)[(size_t)yj * (size_t)width + xi];
         const double s = 1.0 / 255.0;
         return mk((double)px.x * s, (double)px.y * s, (double)px.z * s);
     }
