@@ -48,6 +48,7 @@ def gpu(rt):
 # any test runs, and tests/test_bench_launch.py only collects its result.
 def pytest_sessionstart(session):
     session.config._bench_rehearsal = None
+    session.config._cli_run = None
     if (session.config.getoption("-m") or "").strip() != "gpu":
         return
     import subprocess
@@ -60,6 +61,14 @@ def pytest_sessionstart(session):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--spp", "64", "--no-cpu-baseline"]
     session.config._bench_rehearsal = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=log, env=env, text=True, cwd=ROOT)
+    # ... and the headless CLI end to end (-c/-s/--image-action png, the reference's flags), for the same reason
+    import tempfile
+    out = tempfile.mkdtemp(prefix="rt_cli_")
+    exe = os.path.join(ROOT, "racer-tracer_amd", "bin", "racer-tracer-amd")
+    cli = [exe, "-c", os.path.join(ROOT, "scenes", "config_c1.yml"), "-s", os.path.join(ROOT, "scenes", "three_balls.yml"),
+           "--image-action", "png", "--seed", "1"]
+    session.config._cli_run = (out, subprocess.run(cli, capture_output=True, text=True, cwd=out, timeout=600))
+    session.config._cli_two_devices = subprocess.run(cli + ["--devices", "2"], capture_output=True, text=True, cwd=out, timeout=600)
 
 
 def pytest_sessionfinish(session, exitstatus):

@@ -44,3 +44,31 @@ def test_bench_self_launches_two_ranks(request, gpu):
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0
     assert out["rehearsal_frame_matches_single_rank"] is True
     assert out["config"]["workload"].startswith("cornell_box.yml 1920x1080 64spp")
+
+
+@pytest.mark.gpu
+def test_cli_renders_and_saves_the_reference_png(request, gpu, orc, rt):
+    """racer-tracer-amd -c config -s scene --image-action png: render, tone map, `<SHA-256>.png` (main.rs:148-158,
+    png.rs:19-55); the picture is the oracle's.  With --devices 2 the frame is sharded over two GPUs of the process
+    (rt_render_frame_multi) - or, on a one-GPU box, refused with the device-index error, not a crash."""
+    import importlib
+    import numpy as np
+    from PIL import Image
+    if request.config._cli_run is None:
+        pytest.skip("the CLI is started by `pytest -m gpu` (conftest.pytest_sessionstart)")
+    out, run = request.config._cli_run
+    assert run.returncode == 0 and "Saved image to" in run.stderr, run.stderr[-2000:]
+    pngs = sorted(f for f in os.listdir(out) if f.endswith(".png") and len(f) == 68)
+    host = importlib.import_module("racer-tracer_amd.host")
+    s = host.Session(os.path.join(ROOT, "scenes", "config_c1.yml"), scene=os.path.join(ROOT, "scenes", "three_balls.yml"))
+    ref, _ = orc.render(s.desc, s.camera, s.params)
+    want = orc.pack_rgba8(s.tone_map(ref))
+    two = request.config._cli_two_devices
+    if rt.device_count() >= 2:
+        assert two.returncode == 0 and len(pngs) == 1     # the same bytes -> the same SHA-256 name
+    else:
+        assert two.returncode == rt.abi.RT_ERR_INVALID_ARGUMENT and "device index" in two.stderr and len(pngs) == 1
+    img = np.array(Image.open(os.path.join(out, pngs[0])))
+    assert img.shape == want.shape == (225, 400, 4)
+    assert np.abs(img.astype(int) - want.astype(int)).max() <= 1 and (img != want).mean() < 1e-3
+    assert pngs[0] == host.sha256_hex(img.tobytes()) + ".png"
