@@ -112,17 +112,27 @@ struct NoiseSlots {
     int perlin[8];     // ... and gradient table
     double term[8][8]; // 0.5^o * noise(2^o * p) of the round's octaves, summed in order by the requester
 };
-struct NoNoiseSlots {};
+// A request of the cooperative samplers: {pixel, sample, segment, next candidate}
+struct alignas(16) Req4 { // one 128-bit LDS access
+    uint32_t x, y, z, w;
+};
+// The sampler's request slots and the turbulence slots are never live at the same time (the Noise rounds of
+// an iteration end before its sampler rounds begin, and both finish with what they posted), so they share
+// their LDS: the textured variants — the BVH ones above all, whose node array already fills LDS to
+// three blocks per CU — cost no more LDS than the plain ones.
+union SamplerScratch {
+    Req4 req[64];
+    NoiseSlots noise;
+};
 
 // Per-wave scratch in LDS.  HAS_TIME: the scene has MovingSpheres (PRIMS_ANY variants).
 // NBUF: batches of camera samples kept (2, or 1 for the BVH variants, whose node array wants the LDS).
-template <bool HAS_TIME, int NBUF, bool TEXTURED> struct WaveLds {
-    typename std::conditional<TEXTURED, NoiseSlots, NoNoiseSlots>::type noise;
+template <bool HAS_TIME, int NBUF> struct WaveLds {
     // per pixel of the item's tile: upper_left_corner + u * horizontal with the pixel's ONE
     // horizontal jitter u = (px + ju) / (W - 1) (cpu.rs:35-36, camera.rs:331)
     double base[64][3];
     double sum[64][3];  // per-pixel radiance sums of the current item
-    uint4 req[64];      // cooperative sampler requests: {pixel, sample, segment, next candidate}
+    SamplerScratch scratch; // cooperative sampler requests / Noise lookups
     int pix_of[64];     // pool slot -> lane-order pixel index, for tiles cut by the image edge
     // Camera samples of the pool entries, drawn 64 entries at a time by the WHOLE wave
     // (prepare_batch below): entry w sits in slot w & 63 of buffer (w >> 6) & (NBUF - 1).
@@ -138,7 +148,7 @@ template <bool HAS_TIME, int NBUF, bool TEXTURED> struct WaveLds {
 // at the same stream position in the next call.
 __device__ __forceinline__ bool coop_random_in_unit_sphere(bool need, uint32_t pixel, uint32_t sample, uint32_t seg,
                                                            uint32_t &base, uint32_t k0, uint32_t k1, int lane,
-                                                           uint4 *req, int max_rounds, d3 &result) {
+                                                           Req4 *req, int max_rounds, d3 &result) {
     bool have = false;
     uint64_t pending = __ballot(need);
     for (int round = 0; round < max_rounds && pending != 0; ++round) {
@@ -162,11 +172,11 @@ __device__ __forceinline__ bool coop_random_in_unit_sphere(bool need, uint32_t p
             continue;
         }
         const int rank = lane_rank(pending);
-        if (need) req[rank] = make_uint4(pixel, sample, seg, base);
+        if (need) req[rank] = Req4{pixel, sample, seg, base};
         const int j = lane >> lg;              // request served by this lane
         const int c = lane & ((1 << lg) - 1);  // candidate offset inside the group
         const bool serving = j < n;
-        const uint4 r = req[serving ? j : 0];
+        const Req4 r = req[serving ? j : 0];
         const uint32_t i = r.w + (uint32_t)c;  // candidate index: blocks 2i and 2i+1 (rt_rng.h)
         const u4 b0 = philox4x32(r.x, r.y, (r.z << 8) | RT_RNG_SCATTER, 2u * i, k0, k1);
         const u4 b1 = philox4x32(r.x, r.y, (r.z << 8) | RT_RNG_SCATTER, 2u * i + 1u, k0, k1);
@@ -195,7 +205,7 @@ __device__ __forceinline__ bool coop_random_in_unit_sphere(bool need, uint32_t p
 // Philox block per candidate (block i -> x, y), first accepted candidate in stream
 // order.  Runs until every request is settled (a fresh path needs its ray now).
 __device__ __forceinline__ void coop_random_in_unit_disk(bool need, uint32_t pixel, uint32_t sample, uint32_t k0,
-                                                         uint32_t k1, int lane, uint4 *req, double &out_x,
+                                                         uint32_t k1, int lane, Req4 *req, double &out_x,
                                                          double &out_y) {
     uint32_t base = 0;
     uint64_t pending = __ballot(need);
@@ -218,11 +228,11 @@ __device__ __forceinline__ void coop_random_in_unit_disk(bool need, uint32_t pix
             continue;
         }
         const int rank = lane_rank(pending);
-        if (need) req[rank] = make_uint4(pixel, sample, 0u, base);
+        if (need) req[rank] = Req4{pixel, sample, 0u, base};
         const int j = lane >> lg;
         const int c = lane & ((1 << lg) - 1);
         const bool serving = j < n;
-        const uint4 r = req[serving ? j : 0];
+        const Req4 r = req[serving ? j : 0];
         const u4 b = philox4x32(r.x, r.y, RT_RNG_LENS, r.w + (uint32_t)c, k0, k1);
         const double x = sym53(b.a, b.b), y = sym53(b.c, b.d);
         const uint64_t accepted = __ballot(serving && x * x + y * y < 1.0);
@@ -303,7 +313,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
     // boundary; the BVH variants keep one (their node array wants the LDS: three resident blocks
     // instead of two on the `random` scene) and a hand-out stops at the end of its batch.
     constexpr int NBUF = BVH ? 1 : 2;
-    __shared__ WaveLds<PRIMS == PRIMS_ANY, NBUF, TEXTURED> lds_all[4];
+    __shared__ WaveLds<PRIMS == PRIMS_ANY, NBUF> lds_all[4];
     // The gradients of the first Perlin table (6 KB) are staged in LDS once per block when the
     // permutation tables are the identity (always, in the reference: noise.rs:121-130): the 56
     // random gradient fetches of a marble lookup then hit LDS instead of the vector memory
@@ -358,7 +368,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
-    WaveLds<PRIMS == PRIMS_ANY, NBUF, TEXTURED> &L = lds_all[threadIdx.x >> 6];
+    WaveLds<PRIMS == PRIMS_ANY, NBUF> &L = lds_all[threadIdx.x >> 6];
     unsigned int n_segments = 0, n_started = 0;
 
     RT_REGION_DECL
@@ -444,7 +454,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
             // camera.rs:327: aperture 0 multiplies the disk by 0, so its draws are dead and skipped
             if (K->cam.lens_radius != 0.0) {
                 double lx = 0.0, ly = 0.0;
-                coop_random_in_unit_disk(in_pool, pixel_b, sample_b, A.seed_lo, A.seed_hi, lane, L.req, lx, ly);
+                coop_random_in_unit_disk(in_pool, pixel_b, sample_b, A.seed_lo, A.seed_hi, lane, L.scratch.req, lx, ly);
                 L.lens[buf][lane][0] = lx;
                 L.lens[buf][lane][1] = ly;
             }
@@ -640,7 +650,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
                 if (__ballot(lookup) != 0) {
                     const Texture *tt = BVH ? A.textures : lds_textures;
                     const double turb = coop_noise_turbulence(lookup, hit_point, lookup ? tt[noise_tex].depth : 0,
-                                                              lookup ? tt[noise_tex].perlin : 0, A, lds_perlin, lane, L.noise);
+                                                              lookup ? tt[noise_tex].perlin : 0, A, lds_perlin, lane, L.scratch.noise);
                     if (lookup) {
                         const d3 tex = noise_colour(tt[noise_tex], hit_point, turb);
                         if (ended) contrib = T * tex; // DiffuseLight: the only material that ends on a textured hit
@@ -651,7 +661,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
             RT_REGION(10); // Noise rounds
             d3 sph = mk(0.0, 0.0, 0.0);
             if (coop_random_in_unit_sphere(waiting, rng.pixel, rng.sample, seg, cand_base, A.seed_lo, A.seed_hi, lane,
-                                           L.req, (TEXTURED || SPECULAR) ? 4 : 2, sph)) {
+                                           L.scratch.req, (TEXTURED || SPECULAR) ? 4 : 2, sph)) {
                 waiting = false;
                 finish = true;
             }
