@@ -197,6 +197,7 @@ void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtd
     a.bvh_prim_index = s->bvh_prim_index.ptr;
     a.n_bvh_nodes = s->n_bvh_nodes;
     a.bvh_lds_nodes = s->bvh_nodes_in_lds ? s->n_bvh_nodes : 0;
+    for (int g = 0; g < 3; ++g) a.rect_end[g] = s->rect_end[g];
 #ifdef RT_DEVELOPER_KNOBS // throw-away kernel knobs of the developer build (tools/perf_ab.sh)
     for (int k = 0; k < 4; ++k) {
         char name[16];
@@ -504,6 +505,17 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
     // the linear-loop variants keep the whole primitive table in LDS
     if (!s->use_bvh && (size_t)d->n_primitives * sizeof(rtdev::Prim) > 120 * 1024)
         return fail(RT_ERR_UNSUPPORTED, "RT_HIT_LINEAR: the primitive table does not fit in LDS");
+    if (only_rects && !s->use_bvh) { // linear loop: group the table by plane (rt_device_types.h: rect_end); the order inside a group is kept
+        std::vector<rtdev::Prim> sorted;
+        sorted.reserve(prims.size());
+        const int order[3] = {RT_PRIM_XY_RECT, RT_PRIM_XZ_RECT, RT_PRIM_YZ_RECT};
+        for (int g = 0; g < 3; ++g) {
+            for (const rtdev::Prim &q : prims)
+                if (q.kind == order[g]) sorted.push_back(q);
+            s->rect_end[g] = (int)sorted.size();
+        }
+        prims.swap(sorted);
+    }
     if (s->use_bvh) {
         rtdev::BvhBuild bvh = rtdev::build_bvh(d->primitives, d->n_primitives);
         if ((rc = upload(s->bvh_nodes, bvh.nodes)) != RT_OK) return rc;

@@ -547,13 +547,37 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
                         };
                         // two records per scalar-load wait: the table's latency is paid n/2 times, not n
                         // (C3 +2.8 %, C2 +3.8 %; three per wait run out of SGPRs and lose it again)
-                        int i = 0;
-                        for (; i + 1 < A.n_prims; i += 2) {
-                            const Prim pa = load_prim_uniform(A.prims, i), pb = load_prim_uniform(A.prims, i + 1);
-                            test(pa, i);
-                            test(pb, i + 1);
+                        if (PRIMS == PRIMS_RECTS && !BVH) {
+                            // The table is grouped by plane (rect_end): one straight-line test per group, the plane a
+                            // compile-time constant, instead of a scalar switch on the kind of every record.
+                            auto test_plane = [&](auto axis, const Prim &P, int i) {
+                                double t;
+                                if (rect_t<true>(decltype(axis)::value, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, 0.001, best_t, t)) {
+                                    best_t = t;
+                                    best = i;
+                                }
+                            };
+                            auto group = [&](auto axis, int begin, int end) {
+                                int i = begin;
+                                for (; i + 1 < end; i += 2) {
+                                    const Prim pa = load_prim_uniform(A.prims, i), pb = load_prim_uniform(A.prims, i + 1);
+                                    test_plane(axis, pa, i);
+                                    test_plane(axis, pb, i + 1);
+                                }
+                                if (i < end) test_plane(axis, load_prim_uniform(A.prims, i), i);
+                            };
+                            group(std::integral_constant<int, 2>(), 0, A.rect_end[0]);              // XY
+                            group(std::integral_constant<int, 1>(), A.rect_end[0], A.rect_end[1]);  // XZ
+                            group(std::integral_constant<int, 0>(), A.rect_end[1], A.rect_end[2]);  // YZ
+                        } else {
+                            int i = 0;
+                            for (; i + 1 < A.n_prims; i += 2) {
+                                const Prim pa = load_prim_uniform(A.prims, i), pb = load_prim_uniform(A.prims, i + 1);
+                                test(pa, i);
+                                test(pb, i + 1);
+                            }
+                            if (i < A.n_prims) test(load_prim_uniform(A.prims, i), i);
                         }
-                        if (i < A.n_prims) test(load_prim_uniform(A.prims, i), i);
                     }
                     RT_REGION(3); // closest hit
                     if (best < 0) { // background_color.rs:27-33 / :45-48
