@@ -86,6 +86,21 @@ __device__ __forceinline__ double rsqrt_f64(double x) {
     h = fma(h, r, h);
     return h + h;
 }
+// sqrt(x) for x >= 0 to ~1 ulp from the reciprocal-square-root seed: the library's correctly rounded sqrt is
+// this plus a range-scaling prologue/epilogue for arguments near the ends of the exponent range (18
+// instructions against 11), and the sphere test (sphere.rs:47) takes one square root per candidate sphere.
+__device__ __forceinline__ double sqrt_fast(double x) {
+#ifdef RT_EXACT_DIV
+    return sqrt(x);
+#endif
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    g = fma(fma(-g, g, x), h, g);
+    return x == 0.0 ? 0.0 : g; // rsq(0) = inf
+}
 // vec3.rs:79-85 unit_vector with one reciprocal square root instead of a
 // square root and three divisions
 __device__ __forceinline__ d3 unit_fast(d3 a) {
@@ -259,7 +274,7 @@ __device__ __forceinline__ bool prim_t(const Prim &P, d3 o, d3 d, d3 inv_d, doub
         double c = len2(oc) - P.radius2;
         double disc = half_b * half_b - a * c;
         if (disc < 0.0) return false;
-        double sqrtd = sqrt(disc);
+        double sqrtd = sqrt_fast(disc);
         double root = div_by(-half_b - sqrtd, a, inv_a); // sphere.rs:52 divides by a
         if (root < t_min || t_max < root) {
             root = div_by(-half_b + sqrtd, a, inv_a);
