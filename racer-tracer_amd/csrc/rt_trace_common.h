@@ -352,13 +352,17 @@ __device__ __forceinline__ void closest_hit_bvh(const TraceArgs &A, const BvhNod
     }
 }
 
-// sphere.rs:20-27; out of line: acos/atan2 are large and only image textures read u,v
-__device__ __noinline__ void sphere_uv(d3 outward, double &u, double &v) {
+// sphere.rs:20-27; out of line: acos/atan2 are large and only image textures read u,v.  Returned BY VALUE:
+// with reference parameters the caller's whole Hit record became addressable and lived in scratch memory,
+// written on every hit of every textured variant.
+struct UV {
+    double u, v;
+};
+__device__ __noinline__ UV sphere_uv(d3 outward) {
     const double PI = 3.14159265358979323846;
     double theta = acos(-outward.y);
     double phi = atan2(-outward.z, outward.x) + PI;
-    u = phi / (2.0 * PI);
-    v = theta / PI;
+    return UV{phi / (2.0 * PI), theta / PI};
 }
 
 // Rebuild the HitRecord of the winning primitive (geometry.rs:17-57).
@@ -379,11 +383,19 @@ __device__ __forceinline__ Hit prim_hit_record(const Prim &P, d3 o, d3 d, double
     if (PRIMS == PRIMS_ANY && kind == RT_PRIM_MOVING_SPHERE) {
         const d3 center = ld3(P.p) + ((time - P.rot_sin) * P.rot_cos) * ld3(P.tr);
         d3 outward = (h.point - center) * P.inv_radius; // moving_sphere.rs:75
-        if (TEXTURED && want_uv) sphere_uv(h.point, h.u, h.v); // moving_sphere.rs:76: uv of the POINT (SURVEY B-19)
+        if (TEXTURED && want_uv) { // moving_sphere.rs:76: uv of the POINT (SURVEY B-19)
+            const UV uv = sphere_uv(h.point);
+            h.u = uv.u;
+            h.v = uv.v;
+        }
         set_face_normal(h, dd, outward);
     } else if (PRIMS != PRIMS_RECTS && kind == RT_PRIM_SPHERE) {
         d3 outward = (h.point - ld3(P.p)) * P.inv_radius; // sphere.rs:61
-        if (TEXTURED && want_uv) sphere_uv(outward, h.u, h.v);
+        if (TEXTURED && want_uv) {
+            const UV uv = sphere_uv(outward);
+            h.u = uv.u;
+            h.v = uv.v;
+        }
         set_face_normal(h, dd, outward);
     } else {
         int axis;
