@@ -198,6 +198,7 @@ void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtd
     a.n_bvh_nodes = s->n_bvh_nodes;
     a.bvh_lds_nodes = s->bvh_nodes_in_lds ? s->n_bvh_nodes : 0;
     for (int g = 0; g < 3; ++g) a.rect_end[g] = s->rect_end[g];
+    a.sphere_end = s->sphere_end;
 #ifdef RT_DEVELOPER_KNOBS // throw-away kernel knobs of the developer build (tools/perf_ab.sh)
     for (int k = 0; k < 4; ++k) {
         char name[16];
@@ -505,14 +506,21 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
     // the linear-loop variants keep the whole primitive table in LDS
     if (!s->use_bvh && (size_t)d->n_primitives * sizeof(rtdev::Prim) > 120 * 1024)
         return fail(RT_ERR_UNSUPPORTED, "RT_HIT_LINEAR: the primitive table does not fit in LDS");
-    if (only_rects && !s->use_bvh) { // linear loop: group the table by plane (rt_device_types.h: rect_end); the order inside a group is kept
+    if (!s->use_bvh) { // linear loop: group the table (rt_device_types.h: rect_end, sphere_end); the order inside a group is kept
         std::vector<rtdev::Prim> sorted;
         sorted.reserve(prims.size());
-        const int order[3] = {RT_PRIM_XY_RECT, RT_PRIM_XZ_RECT, RT_PRIM_YZ_RECT};
-        for (int g = 0; g < 3; ++g) {
+        auto group_of = [](const rtdev::Prim &q) {
+            if (q.flags == 0 && q.kind == RT_PRIM_XY_RECT) return 0;
+            if (q.flags == 0 && q.kind == RT_PRIM_XZ_RECT) return 1;
+            if (q.flags == 0 && q.kind == RT_PRIM_YZ_RECT) return 2;
+            if (q.flags == 0 && q.kind == RT_PRIM_SPHERE) return 3;
+            return 4;
+        };
+        for (int g = 0; g < 5; ++g) {
             for (const rtdev::Prim &q : prims)
-                if (q.kind == order[g]) sorted.push_back(q);
-            s->rect_end[g] = (int)sorted.size();
+                if (group_of(q) == g) sorted.push_back(q);
+            if (g < 3) s->rect_end[g] = (int)sorted.size();
+            if (g == 3) s->sphere_end = (int)sorted.size();
         }
         prims.swap(sorted);
     }

@@ -146,10 +146,12 @@ struct TraceArgs {
     const int32_t *bvh_prim_index;
     int32_t n_bvh_nodes;
     int32_t bvh_lds_nodes; // == n_bvh_nodes when the node array is staged in dynamic LDS, else 0
-    // Scenes of untransformed rects only (PRIMS_RECTS): the device table is sorted by plane — XY rects first,
-    // then XZ, then YZ — and rect_end[a] is the end of group a, so that the closest-hit loop runs one
-    // straight-line test per group instead of switching on the kind of every record.
+    // Linear-loop variants: the device table is grouped — untransformed XY rects first, then XZ, then YZ
+    // (rect_end[a] is the end of group a), then untransformed spheres (sphere_end), then everything else
+    // (boxes, moving spheres, wrapped primitives) — so that the closest-hit loop runs one straight-line test
+    // per group instead of a scalar switch on the kind of every record.
     int32_t rect_end[3];
+    int32_t sphere_end;
     int32_t dbg[4];        // developer knobs (env RT_DBG0..3), 0 in production
 };
 

@@ -60,7 +60,8 @@ struct RtScene {
     rtdev::Background bg;
     // kernel specialisation (rt_trace_kernel.hip): 0 rects only, 1 spheres only, 2 anything
     int prims_class = 2;
-    int rect_end[3] = {0, 0, 0}; // prims_class 0: ends of the XY / XZ / YZ groups of the (sorted) device table
+    int rect_end[3] = {0, 0, 0}; // linear loop: ends of the XY / XZ / YZ rect groups of the (grouped) device table
+    int sphere_end = 0;          // ... and of the plain-sphere group behind them
     int textured = 0; // some material's texture is not a plain SolidColor
     int specular = 0; // some material is Metal or Dielectric
 

@@ -550,8 +550,8 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
                         };
                         // two records per scalar-load wait: the table's latency is paid n/2 times, not n
                         // (C3 +2.8 %, C2 +3.8 %; three per wait run out of SGPRs and lose it again)
-                        if (PRIMS == PRIMS_RECTS && !BVH) {
-                            // The table is grouped by plane (rect_end): one straight-line test per group, the plane a
+                        if (PRIMS != PRIMS_SPHERES) {
+                            // The table is grouped (rect_end, sphere_end): one straight-line test per group, the plane a
                             // compile-time constant, instead of a scalar switch on the kind of every record.
                             auto test_plane = [&](auto axis, const Prim &P, int i) {
                                 double t;
@@ -572,6 +572,19 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
                             group(std::integral_constant<int, 2>(), 0, A.rect_end[0]);              // XY
                             group(std::integral_constant<int, 1>(), A.rect_end[0], A.rect_end[1]);  // XZ
                             group(std::integral_constant<int, 0>(), A.rect_end[1], A.rect_end[2]);  // YZ
+                            if (PRIMS == PRIMS_ANY) {
+                                int i = A.rect_end[2];
+                                for (; i < A.sphere_end; ++i) { // plain spheres: sphere.rs:39-59, no switch, no wrapper
+                                    double t;
+                                    int aux;
+                                    if (prim_t<PRIMS_SPHERES>(load_prim_uniform(A.prims, i), o, d, inv_d, inv_a, ray_time, 0.001, best_t, t, aux)) {
+                                        best_t = t;
+                                        best = i;
+                                        best_aux = 0;
+                                    }
+                                }
+                                for (; i < A.n_prims; ++i) test(load_prim_uniform(A.prims, i), i); // boxes, moving spheres, wrapped primitives
+                            }
                         } else {
                             int i = 0;
                             for (; i + 1 < A.n_prims; i += 2) {
