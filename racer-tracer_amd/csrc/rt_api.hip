@@ -41,6 +41,8 @@ using rtapi::Window;
 
 namespace {
 
+constexpr int rtdev_max_chunks = 64; // slices of `partial` a frame may need
+
 int validate_desc(const RtSceneDesc *d) {
     if (!d) return fail(RT_ERR_INVALID_ARGUMENT, "scene description is NULL");
     if (d->n_primitives < 0 || d->n_materials < 0 || d->n_textures < 0 || d->n_images < 0 || d->n_perlins < 0)
@@ -248,12 +250,18 @@ int rtapi::enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderPara
         a.n_tiles = a.tiles_x * ((a.owned_rows + 7) / 8);
         // Sample chunks.  Their boundaries fix the order in which a pixel's samples are summed, so
         // they depend on the sample count ONLY (never on tiling, strips, batches or the device): the
-        // frame is bit-identical for every GPU count.  32 samples per chunk measured best over
-        // 16..512 on cornell_box / three_balls (more above 2048 spp: at most 64 slices).  Finer
-        // chunks for the last samples were tried against the end-of-launch tail and lost: the last
-        // wave ends only 0.34 ms after the first (C3), and small items cost more than that in ramps.
-        int chunk_samples = 32;
-        if ((p->samples + chunk_samples - 1) / chunk_samples > 64) chunk_samples = (p->samples + 63) / 64;
+        // frame is bit-identical for every GPU count.  About two dozen chunks per frame: every item ends in
+        // a tail of ~20 iterations in which its last deep paths die out at a handful of lanes (7.5 % of
+        // C3's iterations with chunks of 32), so long chunks pay - until items become too few and too long
+        // for the end of a launch to balance, which a rank's share of a multi-GPU frame reaches first.
+        // Measured on the 1080p frames (tools/perf_ab.sh RT_POOL_CHUNK=.., tools/strip_share.py), ms per frame /
+        // slowest of 8 shares: C3 (1024 spp) chunks of 32: 96.6 / 13.9, 40: 95.9 / 13.7, 48: 95.1 / 14.0,
+        // 64: 94.7 / 14.1, 88: 94.1 / 14.4; C2 (256 spp) 16: 18.5, 24: 18.5, 32: 18.7, 64: 19.3; C4 (512 spp)
+        // flat from 24 to 48.  spp / 24 serves one GPU and eight.  Fewer slices too: 24 x 49.8 MB per C3 frame
+        // instead of 32, 4.8 GB instead of 12.7 GB for a whole C5 frame.
+        int chunk_samples = ((p->samples + 23) / 24 + 3) / 4 * 4;
+        if (chunk_samples < 16) chunk_samples = 16;
+        if ((p->samples + chunk_samples - 1) / chunk_samples > rtdev_max_chunks) chunk_samples = (p->samples + rtdev_max_chunks - 1) / rtdev_max_chunks;
 #ifdef RT_DEVELOPER_KNOBS // changes the summation order: never in the product build
         if (const char *k = getenv("RT_POOL_CHUNK"))
             if (atoi(k) > 0) chunk_samples = atoi(k);
