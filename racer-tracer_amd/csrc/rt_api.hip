@@ -41,8 +41,6 @@ using rtapi::Window;
 
 namespace {
 
-constexpr int rtdev_max_chunks = 64; // slices of `partial` a frame may need
-
 int validate_desc(const RtSceneDesc *d) {
     if (!d) return fail(RT_ERR_INVALID_ARGUMENT, "scene description is NULL");
     if (d->n_primitives < 0 || d->n_materials < 0 || d->n_textures < 0 || d->n_images < 0 || d->n_perlins < 0)
@@ -130,6 +128,48 @@ int rtapi::check_params(const RtCamera *camera, const RtRenderParams *p) {
 using rtapi::check_params;
 
 namespace {
+
+// SAMPLE CHUNKS.  A work item of the pooled kernel is a tile x a chunk of its samples, and the order in which a
+// pixel's samples are summed follows the chunk boundaries, so they depend on the sample count ONLY (never on
+// tiling, strips, batches or the device): the frame is bit-identical for every GPU count.
+// Returns the start sample of every chunk plus the total (size = chunks + 1).
+// * About two dozen full-length chunks per frame: every item ends in a tail of ~20 iterations in which its last
+//   deep paths die out at a handful of lanes (7.5 % of C3's iterations with chunks of 32), so long chunks pay -
+//   until items become too few and too long for the end of a launch to balance, which a rank's share of a
+//   multi-GPU frame reaches first.  Measured on the 1080p frames (tools/perf_ab.sh RT_POOL_CHUNK=..,
+//   tools/strip_share.py), ms per frame / slowest of 8 shares: C3 (1024 spp) chunks of 32: 96.6 / 13.9,
+//   40: 95.9 / 13.7, 48: 95.1 / 14.0, 64: 94.7 / 14.1, 88: 94.1 / 14.4; C2 (256 spp) 16: 18.5, 24: 18.5, 32: 18.7,
+//   64: 19.3; C4 (512 spp) flat from 24 to 48.  spp / 24 serves one GPU and eight.
+// * The last one to two chunk lengths of samples are cut into ever shorter chunks (halving down to 4 samples): items
+//   are queued chunk-major, so a launch ends on small items and its waves finish together.
+std::vector<int> chunk_plan(int samples) {
+    int full = ((samples + 23) / 24 + 3) / 4 * 4;
+    if (full < 16) full = 16;
+#ifdef RT_DEVELOPER_KNOBS // changes the summation order: never in the product build
+    if (const char *k = getenv("RT_POOL_CHUNK"))
+        if (atoi(k) > 0) full = atoi(k);
+#endif
+    std::vector<int> starts;
+    int at = 0;
+    while (samples - at >= 2 * full && (int)starts.size() < rtdev::RT_MAX_CHUNKS - 8) {
+        starts.push_back(at);
+        at += full;
+    }
+#ifdef RT_DEVELOPER_KNOBS
+    const bool taper = getenv("RT_POOL_NO_TAPER") == nullptr;
+#else
+    const bool taper = true;
+#endif
+    while (samples - at > 8 && taper) {
+        starts.push_back(at);
+        const int rest = samples - at;
+        at += rest >= 2 * full ? full : (rest / 2 + 3) / 4 * 4; // more than 2 x full only when the chunk table is full
+        if ((int)starts.size() >= rtdev::RT_MAX_CHUNKS - 1) break;
+    }
+    if (at < samples) starts.push_back(at);
+    starts.push_back(samples);
+    return starts;
+}
 
 void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtdev::TraceArgs &a) {
     memset(&a, 0, sizeof a);
@@ -248,35 +288,29 @@ int rtapi::enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderPara
         }
         a.tiles_x = ((a.cover_w - a.x_origin) / a.step_x + 7) / 8; // grid cells per row of the window
         a.n_tiles = a.tiles_x * ((a.owned_rows + 7) / 8);
-        // Sample chunks.  Their boundaries fix the order in which a pixel's samples are summed, so
-        // they depend on the sample count ONLY (never on tiling, strips, batches or the device): the
-        // frame is bit-identical for every GPU count.  About two dozen chunks per frame: every item ends in
-        // a tail of ~20 iterations in which its last deep paths die out at a handful of lanes (7.5 % of
-        // C3's iterations with chunks of 32), so long chunks pay - until items become too few and too long
-        // for the end of a launch to balance, which a rank's share of a multi-GPU frame reaches first.
-        // Measured on the 1080p frames (tools/perf_ab.sh RT_POOL_CHUNK=.., tools/strip_share.py), ms per frame /
-        // slowest of 8 shares: C3 (1024 spp) chunks of 32: 96.6 / 13.9, 40: 95.9 / 13.7, 48: 95.1 / 14.0,
-        // 64: 94.7 / 14.1, 88: 94.1 / 14.4; C2 (256 spp) 16: 18.5, 24: 18.5, 32: 18.7, 64: 19.3; C4 (512 spp)
-        // flat from 24 to 48.  spp / 24 serves one GPU and eight.  Fewer slices too: 24 x 49.8 MB per C3 frame
-        // instead of 32, 4.8 GB instead of 12.7 GB for a whole C5 frame.
-        int chunk_samples = ((p->samples + 23) / 24 + 3) / 4 * 4;
-        if (chunk_samples < 16) chunk_samples = 16;
-        if ((p->samples + chunk_samples - 1) / chunk_samples > rtdev_max_chunks) chunk_samples = (p->samples + rtdev_max_chunks - 1) / rtdev_max_chunks;
-#ifdef RT_DEVELOPER_KNOBS // changes the summation order: never in the product build
-        if (const char *k = getenv("RT_POOL_CHUNK"))
-            if (atoi(k) > 0) chunk_samples = atoi(k);
-#endif
-        if (chunk_samples > p->samples) chunk_samples = p->samples;
-        // sample batches (cancel polling) are cut on chunk boundaries, so batching changes nothing either
-        batch = (batch + chunk_samples - 1) / chunk_samples * chunk_samples;
-        if (batch > p->samples) batch = p->samples;
-        const int n_batches = (p->samples + batch - 1) / batch;
-        const int total_chunks = (p->samples + chunk_samples - 1) / chunk_samples;
+        // Sample chunks (chunk_plan above).  Sample batches (cancel polling) are cut on chunk boundaries, so
+        // batching changes nothing either.
+        const std::vector<int> starts = chunk_plan(p->samples);
+        const int total_chunks = (int)starts.size() - 1;
+        for (int c = 0; c <= total_chunks; ++c) a.chunk_start[c] = starts[(size_t)c];
+        a.chunk_samples = starts[1] - starts[0];
+        struct Launch {
+            int first_chunk, n_chunks;
+        };
+        std::vector<Launch> plan;
+        for (int c = 0; c < total_chunks;) {
+            Launch l{c, 0};
+            while (c < total_chunks && (l.n_chunks == 0 || starts[(size_t)c] - starts[(size_t)l.first_chunk] < batch)) {
+                ++l.n_chunks;
+                ++c;
+            }
+            plan.push_back(l);
+        }
+        const int n_batches = (int)plan.size();
         if (s->partial.count < n * (size_t)total_chunks) RT_HIP(s->partial.alloc(n * (size_t)total_chunks));
         const size_t queue_slots = (size_t)n_batches * (size_t)win.count;
         if (win.index == 0 && s->queue.count < queue_slots) RT_HIP(s->queue.alloc(queue_slots));
         a.partial = s->partial.ptr;
-        a.chunk_samples = chunk_samples;
         if (win.index == 0) {
             RT_HIP(hipMemsetAsync(s->segments.ptr, 0, rtdev::RT_STAT_SLOTS * sizeof(unsigned long long), stream));
 #ifdef RT_PROFILE_REGIONS
@@ -288,12 +322,12 @@ int rtapi::enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderPara
         }
         // a slice is only written for the pixels a launch covers; unowned rows are skipped by the resolve
         int chunks_done = 0;
-        for (int b = 0; b < p->samples; b += batch) {
+        for (const Launch &l : plan) {
             if (cancel && *cancel) return RT_ERR_CANCEL_EVENT;
-            a.sample_begin = b;
-            a.sample_end = b + batch < p->samples ? b + batch : p->samples;
-            a.n_chunks = (a.sample_end - a.sample_begin + chunk_samples - 1) / chunk_samples;
-            a.chunk_base = chunks_done;
+            a.sample_begin = starts[(size_t)l.first_chunk];
+            a.sample_end = starts[(size_t)(l.first_chunk + l.n_chunks)];
+            a.n_chunks = l.n_chunks;
+            a.chunk_base = l.first_chunk;
             a.n_items = (uint32_t)a.n_chunks * (uint32_t)a.n_tiles;
             a.queue = s->queue.ptr + (size_t)win.index * (size_t)n_batches + launches;
             unsigned blocks = (unsigned)(s->num_cus * s->pool_blocks_per_cu);

@@ -103,6 +103,8 @@ enum {
     RT_STAT_SLOTS = 42
 };
 
+enum { RT_MAX_CHUNKS = 64 }; // a frame's samples are cut into at most this many chunks (slices of `partial`)
+
 // Kernel argument block (passed by value -> kernarg segment, scalar loads).
 struct TraceArgs {
     const Prim *prims;
@@ -131,7 +133,10 @@ struct TraceArgs {
     uint32_t n_items;
     int32_t n_chunks;            // chunks in this launch
     int32_t chunk_base;          // index of this launch's first chunk in `partial`
-    int32_t chunk_samples;       // samples per chunk (the last one may be shorter)
+    int32_t chunk_samples;       // samples per full-length chunk (informational; the kernel reads chunk_start)
+    // Chunk c of the frame covers the samples [chunk_start[c], chunk_start[c + 1]): full-length chunks first, then a
+    // taper of ever shorter ones, so that the last items of a launch are small (rt_api.hip: chunk_plan).
+    int32_t chunk_start[RT_MAX_CHUNKS + 1];
     int32_t tiles_x, n_tiles;    // 8x8 tiles over width x owned_rows
     // cpu.rs:36,40 divide by (W-1) and (H-1); the pooled kernel multiplies by these
     double inv_width_m1, inv_height_m1;

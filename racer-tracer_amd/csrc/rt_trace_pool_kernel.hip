@@ -385,8 +385,12 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
         const uint32_t tile = item - chunk * (uint32_t)A.n_tiles;
         const int ty = (int)(tile / (uint32_t)A.tiles_x);
         const int tx = (int)tile - ty * A.tiles_x;
-        const int smp0 = A.sample_begin + (int)chunk * A.chunk_samples;
-        const int n_smp = min(A.chunk_samples, A.sample_end - smp0);
+        int smp0, n_smp; // the chunk's samples (chunk = index within this launch)
+        {
+            const RT_CONSTANT TraceArgs *K = kernargs_here();
+            smp0 = K->chunk_start[A.chunk_base + (int)chunk];
+            n_smp = K->chunk_start[A.chunk_base + (int)chunk + 1] - smp0;
+        }
 
         // ---- this lane's pixel of the tile (used for the pool table and the final store)
         // (step_x/step_y > 1: the preview renderer, cpu_scaled.rs — the grid cell is the
