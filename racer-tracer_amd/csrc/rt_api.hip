@@ -133,18 +133,19 @@ namespace {
 // pixel's samples are summed follows the chunk boundaries, so they depend on the sample count ONLY (never on
 // tiling, strips, batches or the device): the frame is bit-identical for every GPU count.
 // Returns the start sample of every chunk plus the total (size = chunks + 1).
-// * About two dozen full-length chunks per frame: every item ends in a tail of ~20 iterations in which its last
+// * About sixteen full-length chunks per frame: every item ends in a tail of ~20 iterations in which its last
 //   deep paths die out at a handful of lanes (7.5 % of C3's iterations with chunks of 32), so long chunks pay -
 //   until items become too few and too long for the end of a launch to balance, which a rank's share of a
-//   multi-GPU frame reaches first.  Measured on the 1080p frames (tools/perf_ab.sh RT_POOL_CHUNK=..,
-//   tools/strip_share.py), ms per frame / slowest of 8 shares: C3 (1024 spp) chunks of 32: 96.6 / 13.9,
-//   40: 95.9 / 13.7, 48: 95.1 / 14.0, 64: 94.7 / 14.1, 88: 94.1 / 14.4; C2 (256 spp) 16: 18.5, 24: 18.5, 32: 18.7,
-//   64: 19.3; C4 (512 spp) flat from 24 to 48.  spp / 24 serves one GPU and eight.
+//   multi-GPU frame reaches first.  Measured on the 1080p frames with the taper below in place
+//   (tools/perf_ab.sh RT_POOL_CHUNK=.., tools/strip_share.py), ms per frame / slowest of 8 shares: C3 (1024 spp)
+//   full chunks of 44: 94.4 / 13.4, 64: 93.4 / 13.6, 88: 92.9 / 13.8, 128: 92.5 / 14.4 (round 1's fixed 32 without
+//   taper: 96.6 / 13.9); C2 (256 spp) 16: 18.5, 24: 18.3, 32: 18.6; C4 (512 spp) 24: 59.8, 32: 59.4, 44: 59.4, 64: 59.8.
+//   spp / 16, at least 24, serves one GPU and eight.
 // * The last one to two chunk lengths of samples are cut into ever shorter chunks (halving down to 4 samples): items
 //   are queued chunk-major, so a launch ends on small items and its waves finish together.
 std::vector<int> chunk_plan(int samples) {
-    int full = ((samples + 23) / 24 + 3) / 4 * 4;
-    if (full < 16) full = 16;
+    int full = ((samples + 15) / 16 + 3) / 4 * 4;
+    if (full < 24) full = 24;
 #ifdef RT_DEVELOPER_KNOBS // changes the summation order: never in the product build
     if (const char *k = getenv("RT_POOL_CHUNK"))
         if (atoi(k) > 0) full = atoi(k);
