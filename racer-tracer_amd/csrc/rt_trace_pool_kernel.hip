@@ -395,10 +395,19 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
         // ---- this lane's pixel of the tile (used for the pool table and the final store)
         // (step_x/step_y > 1: the preview renderer, cpu_scaled.rs — the grid cell is the
         // top-left pixel of a block, the resolve pass fills the block)
+        // Image row of the tile's first row.  With strips of a multiple of 8 rows (what every multi-GPU host here
+        // uses) a tile lies inside ONE strip, so the owned-row -> image-row map is one scalar division per item;
+        // other strip heights take the per-lane division.
+        const bool rows_aligned = A.strip_count <= 1 || (A.strip_rows & 7) == 0;
+        int tile_py0 = ty * 8 * A.step_y;
+        if (A.strip_count > 1 && rows_aligned) {
+            const int q = (ty * 8) / A.strip_rows; // wave-uniform
+            tile_py0 = (q * A.strip_count + A.strip_index) * A.strip_rows + (ty * 8 - q * A.strip_rows);
+        }
         const int my_px = A.x_origin + (tx * 8 + (lane & 7)) * A.step_x;
         const int my_vrow = ty * 8 + (lane >> 3);
-        int my_py = my_vrow * A.step_y;
-        if (A.strip_count > 1)
+        int my_py = tile_py0 + (lane >> 3) * A.step_y;
+        if (!rows_aligned)
             my_py = ((my_vrow / A.strip_rows) * A.strip_count + A.strip_index) * A.strip_rows + my_vrow % A.strip_rows;
         const bool my_valid = my_px < A.cover_w && my_vrow < A.owned_rows && my_py < A.height;
         const uint32_t my_pixel = (uint32_t)my_py * (uint32_t)A.width + (uint32_t)my_px;
@@ -431,10 +440,11 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
                 pix_out = L.pix_of[w - (uint32_t)s_off * (uint32_t)n_valid];
             }
             const int px = A.x_origin + (tx * 8 + (pix_out & 7)) * A.step_x;
-            const int vrow = ty * 8 + (pix_out >> 3);
-            py_out = vrow * A.step_y;
-            if (A.strip_count > 1)
+            py_out = tile_py0 + (pix_out >> 3) * A.step_y;
+            if (!rows_aligned) {
+                const int vrow = ty * 8 + (pix_out >> 3);
                 py_out = ((vrow / A.strip_rows) * A.strip_count + A.strip_index) * A.strip_rows + vrow % A.strip_rows;
+            }
             pixel_out = (uint32_t)py_out * (uint32_t)A.width + (uint32_t)px;
             sample_out = (uint32_t)(smp0 + s_off);
         };
