@@ -666,7 +666,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
                             const double ratio = h.front ? 1.0 / M.ior : M.ior;
                             const d3 ud = unit_fast(d);
                             const double cos_theta = fmin(dot(-ud, h.normal), 1.0);
-                            const double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+                            const double sin_theta = sqrt_fast(1.0 - cos_theta * cos_theta);
                             bool reflect_it = ratio * sin_theta > 1.0;
                             if (!reflect_it) { // the draw happens only when refraction is possible
                                 double r0 = (1.0 - ratio) / (1.0 + ratio);
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
                                 d = ud - (2.0 * dot(ud, h.normal)) * h.normal;
                             } else { // vec3.rs:416-422
                                 const d3 perp = ratio * (ud + cos_theta * h.normal);
-                                d = perp + (-sqrt(fabs(1.0 - len2(perp)))) * h.normal;
+                                d = perp + (-sqrt_fast(fabs(1.0 - len2(perp)))) * h.normal;
                             }
                             o = h.point;
                             scattered = true;
