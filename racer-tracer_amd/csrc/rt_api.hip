@@ -485,6 +485,13 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
         q.tex_kind = -1;
         q.fuzz = m.fuzz;
         q.ior = m.refraction_index;
+        if (m.kind == RT_MAT_DIELECTRIC) { // rt_device_types.h: the per-hit quotients, once
+            const double ior = m.refraction_index;
+            q.color[0] = 1.0 / ior;
+            const double front = (1.0 - q.color[0]) / (1.0 + q.color[0]), back = (1.0 - ior) / (1.0 + ior);
+            q.color[1] = front * front;
+            q.color[2] = back * back;
+        }
         if (m.kind != RT_MAT_DIELECTRIC) {
             const RtTexture &t = d->textures[m.texture];
             q.tex_kind = t.kind;

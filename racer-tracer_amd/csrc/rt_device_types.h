@@ -18,7 +18,10 @@ struct alignas(16) Material { // 64 B
     int32_t needs_uv;         // texture tree contains an Image texture
     double fuzz;
     double ior;
-    double color[3];          // the texture's colour when tex_kind == SolidColor
+    // the texture's colour when tex_kind == SolidColor; for a Dielectric (no texture) the three quotients
+    // dialectric.rs:26,17-19 forms on every hit, formed once at upload with the same IEEE divisions:
+    // color[0] = 1 / ior, color[1] = ((1 - 1/ior) / (1 + 1/ior))^2 (front face), color[2] = ((1 - ior) / (1 + ior))^2
+    double color[3];
     double _pad;
 };
 static_assert(sizeof(Material) == 64, "Material must be 64 bytes");

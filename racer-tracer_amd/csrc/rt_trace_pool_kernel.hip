@@ -663,14 +663,13 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
                             waiting = fuzz != 0.0; // fuzz 0 multiplies the sample by 0: its draws are dead
                             finish = !waiting;
                         } else if (SPECULAR) { // dialectric.rs:25-55
-                            const double ratio = h.front ? 1.0 / M.ior : M.ior;
+                            const double ratio = h.front ? M.color[0] : M.ior; // 1 / ior, divided at upload
                             const d3 ud = unit_fast(d);
                             const double cos_theta = fmin(dot(-ud, h.normal), 1.0);
                             const double sin_theta = sqrt_fast(1.0 - cos_theta * cos_theta);
                             bool reflect_it = ratio * sin_theta > 1.0;
                             if (!reflect_it) { // the draw happens only when refraction is possible
-                                double r0 = (1.0 - ratio) / (1.0 + ratio);
-                                r0 = r0 * r0;
+                                const double r0 = h.front ? M.color[1] : M.color[2]; // ((1 - ratio) / (1 + ratio))^2, at upload
                                 const double m = 1.0 - cos_theta;
                                 const double m2 = m * m;
                                 const double refl = r0 + (1.0 - r0) * (m2 * m2 * m);
