@@ -362,7 +362,11 @@ __device__ __noinline__ UV sphere_uv(d3 outward) {
     const double PI = 3.14159265358979323846;
     double theta = acos(-outward.y);
     double phi = atan2(-outward.z, outward.x) + PI;
+#ifdef RT_EXACT_DIV
     return UV{phi / (2.0 * PI), theta / PI};
+#else
+    return UV{phi * (1.0 / (2.0 * PI)), theta * (1.0 / PI)}; // sphere.rs:25-26 divide; one rounding apart at most
+#endif
 }
 
 // Rebuild the HitRecord of the winning primitive (geometry.rs:17-57).
