@@ -5,7 +5,7 @@
 # 2. bench lines per workload WITH those summaries installed under profiles/ (so the line carries the roofline)
 # 3. rocprofv3 --kernel-trace --stats of the C3 bench command -> kernel_stats.csv
 # 4. region / lane profile of the -DRT_PROFILE_REGIONS build
-# 5. the `random` scene through the BVH and the linear loop, C5 on one card, per-rank shares, launch fixed cost
+# 5. the `random` scene through the BVH and the linear loop, C5 on one card, per-rank shares
 # 6. the N = 2 rehearsal of bench.py's self-launch on one card
 # Copy gpurun_out/<round>/* into profiles/ afterwards.
 set -eo pipefail
@@ -38,7 +38,6 @@ grep -c region "$out/${round}_region_cycles.txt"
 timeout -k 10 300 python3 tools/perf_random.py 64 2>&1 | grep -v amdgpu.ids | tee "$out/${round}_random_scene.txt"
 timeout -k 10 200 python3 tools/c5_check.py 2>&1 | grep -v amdgpu.ids | tee "$out/${round}_c5_check.txt"
 timeout -k 10 200 python3 tools/strip_share.py 2>&1 | grep -v amdgpu.ids | tee "$out/${round}_strip_share.txt"
-timeout -k 10 200 python3 tools/fixed_cost.py 2>&1 | grep -v amdgpu.ids | tee "$out/${round}_fixed_cost.txt"
 BENCH_REHEARSE_ON_ONE_GPU=1 timeout -k 10 300 python3 bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline > "$out/${round}_bench_rehearsal_gpus2.json" 2> "$out/rehearsal.err"
 python3 -c "
 import json
