@@ -61,10 +61,11 @@ def test_one_pixel_dimension_is_refused(rt, gpu, w, h):
         scene.close()
 
 
-@pytest.mark.parametrize("spp", [1, 31, 32, 33, 64, 65, 2049])
+@pytest.mark.parametrize("spp", [1, 7, 8, 9, 31, 32, 33, 47, 48, 49, 64, 65, 200, 257, 1000, 2049])
 def test_sample_counts_around_chunk_boundaries(rt, orc, gpu, spp):
-    """The pooled kernel sums a pixel's samples in chunks of 32 (more above 2048 spp, at most
-    64 slices); any count must give the oracle's frame."""
+    """The pooled kernel sums a pixel's samples in chunks: full-length ones of spp / 16 (at least 24) samples,
+    then a taper of halving chunks down to 8 or fewer (rt_api.hip: chunk_plan); any count must give the
+    oracle's frame."""
     bundle, cam, _ = S.cornell_box()
     w, h = (16, 9) if spp > 100 else (48, 27)
     _parity(rt, orc, bundle, cam, w, h, spp)
