@@ -865,6 +865,9 @@ int rt_scene_last_stats(RtScene *s, RtRenderStats *out) {
         if (c[rtdev::RT_STAT_NOISE])
             fprintf(stderr, "region noise lookups: %.3g wave-iterations with one, %.1f lanes each on average\n", (double)c[rtdev::RT_STAT_NOISE],
                     (double)c[rtdev::RT_STAT_NOISE + 1] / (double)c[rtdev::RT_STAT_NOISE]);
+        if (c[rtdev::RT_STAT_NOISE + 2])
+            fprintf(stderr, "region BVH walk: %.1f nodes visited and %.1f leaf primitives tested per segment\n",
+                    (double)c[rtdev::RT_STAT_NOISE + 2] / (double)segs, (double)c[rtdev::RT_STAT_NOISE + 3] / (double)segs);
         // lanes tracing per iteration: while the pool has paths to hand out / in the item's tail
         for (int part = 0; part < 2; ++part) {
             const unsigned long long *h = c + (part ? rtdev::RT_STAT_LANES_TAIL : rtdev::RT_STAT_LANES_BODY);

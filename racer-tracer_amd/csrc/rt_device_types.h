@@ -102,8 +102,8 @@ enum {
     RT_STAT_WALL = 18,        // first start, last start, first end, last end
     RT_STAT_LANES_BODY = 22,  // 9 bins
     RT_STAT_LANES_TAIL = 31,  // 9 bins
-    RT_STAT_NOISE = 40,       // wave-iterations with a Noise lookup, lookups
-    RT_STAT_SLOTS = 42
+    RT_STAT_NOISE = 40,       // wave-iterations with a Noise lookup, lookups; BVH nodes visited, leaf primitives tested
+    RT_STAT_SLOTS = 44
 };
 
 enum { RT_MAX_CHUNKS = 64 }; // a frame's samples are cut into at most this many chunks (slices of `partial`)

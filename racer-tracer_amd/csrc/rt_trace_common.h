@@ -317,12 +317,13 @@ __device__ __forceinline__ bool prim_t(const Prim &P, d3 o, d3 d, d3 inv_d, doub
 template <int PRIMS>
 __device__ __forceinline__ void closest_hit_bvh(const TraceArgs &A, const BvhNode *nodes, d3 o, d3 d, d3 inv_d,
                                                 double inv_a, double time, double t_min, double &best_t, int &best,
-                                                int &best_aux) {
+                                                int &best_aux, unsigned *walk_stats = nullptr) {
     int i = 0;
     const int n = A.n_bvh_nodes;
     while (i < n) {
         int count = 0, first = 0;
         while (i < n) { // descend / skip until a leaf is entered
+            if (walk_stats) ++walk_stats[0]; // profile build: nodes visited
             const BvhNode *N = &nodes[i];
             const double ax = (N->mn[0] - o.x) * inv_d.x, bx = (N->mx[0] - o.x) * inv_d.x;
             const double ay = (N->mn[1] - o.y) * inv_d.y, by = (N->mx[1] - o.y) * inv_d.y;
@@ -340,6 +341,7 @@ __device__ __forceinline__ void closest_hit_bvh(const TraceArgs &A, const BvhNod
             }
         }
         for (int k = 0; k < count; ++k) { // the leaf's primitives (stored contiguously in leaf order)
+            if (walk_stats) ++walk_stats[1]; // profile build: primitives tested
             const int pi = first + k;
             double t;
             int aux;

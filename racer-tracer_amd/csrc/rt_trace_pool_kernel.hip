@@ -85,7 +85,7 @@ namespace rtdev {
 #define RT_REGION_FLUSH                                                         \
     if (lane < 16) atomicAdd(A.segments + RT_STAT_REGIONS + lane, rt_t_[lane]); \
     if (lane < 18) atomicAdd(A.segments + RT_STAT_LANES_BODY + lane, rt_t_[17 + lane]); \
-    if (lane < 2) atomicAdd(A.segments + RT_STAT_NOISE + lane, rt_t_[35 + lane]); \
+    if (lane < 4) atomicAdd(A.segments + RT_STAT_NOISE + lane, rt_t_[35 + lane]); \
     if (lane == 0) { /* wall clock (100 MHz) of the first/last wave start and end */ \
         const unsigned long long end_ = wall_clock64();                         \
         atomicMin(A.segments + RT_STAT_WALL + 0, rt_wave_start_);               \
@@ -548,10 +548,20 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TE
                     const d3 inv_d = rcp3(d);
                     const double inv_a = PRIMS == PRIMS_RECTS ? 0.0 : rcp_f64(len2(d));
                     if (BVH) {
+#ifdef RT_PROFILE_REGIONS
+                        unsigned walk[2] = {0, 0};
+                        unsigned *walk_stats = walk;
+#else
+                        unsigned *walk_stats = nullptr;
+#endif
                         if (lds_nodes != nullptr)
-                            closest_hit_bvh<PRIMS>(A, lds_nodes, o, d, inv_d, inv_a, ray_time, 0.001, best_t, best, best_aux);
+                            closest_hit_bvh<PRIMS>(A, lds_nodes, o, d, inv_d, inv_a, ray_time, 0.001, best_t, best, best_aux, walk_stats);
                         else
-                            closest_hit_bvh<PRIMS>(A, A.bvh_nodes, o, d, inv_d, inv_a, ray_time, 0.001, best_t, best, best_aux);
+                            closest_hit_bvh<PRIMS>(A, A.bvh_nodes, o, d, inv_d, inv_a, ray_time, 0.001, best_t, best, best_aux, walk_stats);
+#ifdef RT_PROFILE_REGIONS
+                        atomicAdd(&rt_t_[37], (unsigned long long)walk[0]); // per-lane totals (LDS atomics)
+                        atomicAdd(&rt_t_[38], (unsigned long long)walk[1]);
+#endif
                     } else {
                         auto test = [&](const Prim &P, int i) {
                             double t;
