@@ -36,6 +36,7 @@ rm -rf "$out/prof_c3"
 timeout -k 10 300 tools/region_profile.sh c3 c2 c4 > "$out/${round}_region_cycles.txt" 2>&1
 grep -c region "$out/${round}_region_cycles.txt"
 timeout -k 10 300 python3 tools/perf_random.py 64 2>&1 | grep -v amdgpu.ids | tee "$out/${round}_random_scene.txt"
+timeout -k 10 200 python3 tools/quick_perf_yml.py 128 2>&1 | grep -v amdgpu.ids | tee "$out/${round}_all_scenes.txt"
 timeout -k 10 200 python3 tools/c5_check.py 2>&1 | grep -v amdgpu.ids | tee "$out/${round}_c5_check.txt"
 timeout -k 10 200 python3 tools/strip_share.py 2>&1 | grep -v amdgpu.ids | tee "$out/${round}_strip_share.txt"
 BENCH_REHEARSE_ON_ONE_GPU=1 timeout -k 10 300 python3 bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline > "$out/${round}_bench_rehearsal_gpus2.json" 2> "$out/rehearsal.err"
