@@ -860,8 +860,9 @@ int rt_scene_last_stats(RtScene *s, RtRenderStats *out) {
         double total = 0;
         for (int k = 0; k < 16; ++k) total += (double)c[rtdev::RT_STAT_REGIONS + k];
         for (int k = 0; k < 11; ++k)
-            fprintf(stderr, "region %-24s %6.2f %%  (%.3g wave-cycles)\n", names[k], 100.0 * (double)c[rtdev::RT_STAT_REGIONS + k] / total,
-                    (double)c[rtdev::RT_STAT_REGIONS + k]);
+            fprintf(stderr, "region %-24s %6.2f %%  (%.3g wave-cycles, %4.1f lanes active at its closing marker)\n", names[k],
+                    100.0 * (double)c[rtdev::RT_STAT_REGIONS + k] / total, (double)c[rtdev::RT_STAT_REGIONS + k],
+                    c[rtdev::RT_STAT_REGIONS + k] ? (double)c[rtdev::RT_STAT_REGION_LANES + k] / (double)c[rtdev::RT_STAT_REGIONS + k] : 0.0);
         if (c[rtdev::RT_STAT_NOISE])
             fprintf(stderr, "region noise lookups: %.3g wave-iterations with one, %.1f lanes each on average\n", (double)c[rtdev::RT_STAT_NOISE],
                     (double)c[rtdev::RT_STAT_NOISE + 1] / (double)c[rtdev::RT_STAT_NOISE]);

@@ -103,7 +103,8 @@ enum {
     RT_STAT_LANES_BODY = 22,  // 9 bins
     RT_STAT_LANES_TAIL = 31,  // 9 bins
     RT_STAT_NOISE = 40,       // wave-iterations with a Noise lookup, lookups; BVH nodes visited, leaf primitives tested
-    RT_STAT_SLOTS = 44
+    RT_STAT_REGION_LANES = 44, // 16 regions: cycles x active lanes at the region's closing marker
+    RT_STAT_SLOTS = 60
 };
 
 enum { RT_MAX_CHUNKS = 64 }; // a frame's samples are cut into at most this many chunks (slices of `partial`)
