@@ -62,17 +62,19 @@ namespace rtdev {
 #ifdef RT_PROFILE_REGIONS
 // rt_t_[0..15] region cycles, [16] the previous marker, [17..34] the two lane histograms, [35..36] noise counts
 #define RT_REGION_DECL                                                          \
-    __shared__ unsigned long long rt_t_all_[4][40];                             \
+    __shared__ unsigned long long rt_t_all_[4][56];                             \
     unsigned long long *rt_t_ = rt_t_all_[threadIdx.x >> 6];                    \
-    if ((threadIdx.x & 63) < 40) rt_t_[threadIdx.x & 63] = 0;                   \
+    if ((threadIdx.x & 63) < 56) rt_t_[threadIdx.x & 63] = 0;                   \
     if ((threadIdx.x & 63) == 16) rt_t_[16] = __builtin_readcyclecounter();   \
     const unsigned long long rt_wave_start_ = wall_clock64();
 // usable inside divergent code: the first ACTIVE lane books the time since the previous marker
 #define RT_REGION(k)                                                            \
     do {                                                                        \
-        if (lane_rank(__ballot(1)) == 0) {                                      \
+        const unsigned long long act_ = __ballot(1);                            \
+        if (lane_rank(act_) == 0) {                                             \
             const unsigned long long now_ = __builtin_readcyclecounter();       \
             rt_t_[k] += now_ - rt_t_[16];                                       \
+            rt_t_[40 + (k)] += (now_ - rt_t_[16]) * (unsigned long long)__popcll(act_); \
             rt_t_[16] = now_;                                                   \
         }                                                                       \
     } while (0)
@@ -86,6 +88,7 @@ namespace rtdev {
     if (lane < 16) atomicAdd(A.segments + RT_STAT_REGIONS + lane, rt_t_[lane]); \
     if (lane < 18) atomicAdd(A.segments + RT_STAT_LANES_BODY + lane, rt_t_[17 + lane]); \
     if (lane < 4) atomicAdd(A.segments + RT_STAT_NOISE + lane, rt_t_[35 + lane]); \
+    if (lane < 16) atomicAdd(A.segments + RT_STAT_REGION_LANES + lane, rt_t_[40 + lane]); \
     if (lane == 0) { /* wall clock (100 MHz) of the first/last wave start and end */ \
         const unsigned long long end_ = wall_clock64();                         \
         atomicMin(A.segments + RT_STAT_WALL + 0, rt_wave_start_);               \
