@@ -184,6 +184,7 @@ void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtd
     a.n_images = s->n_images;
     a.n_perlins = s->n_perlins;
     a.perlin_identity = s->perlin_identity;
+    a.perlin_in_lds = s->textured && s->n_perlins > 0 && s->perlin_identity;
     a.width = p->width;
     a.height = p->height;
     a.samples = p->samples;
@@ -239,6 +240,11 @@ void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtd
     a.bvh_nodes = s->bvh_nodes.ptr;
     a.bvh_prim_index = s->bvh_prim_index.ptr;
     a.n_bvh_nodes = s->n_bvh_nodes;
+    for (int k = 0; k < 3; ++k) {
+        a.bvh_root_mn[k] = s->bvh_root_mn[k];
+        a.bvh_root_mx[k] = s->bvh_root_mx[k];
+        a.bvh_center[k] = s->bvh_center[k];
+    }
     a.bvh_lds_nodes = s->bvh_nodes_in_lds ? s->n_bvh_nodes : 0;
     for (int g = 0; g < 3; ++g) a.rect_end[g] = s->rect_end[g];
     a.sphere_end = s->sphere_end;
@@ -579,6 +585,11 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
         if ((rc = upload(s->bvh_nodes, bvh.nodes)) != RT_OK) return rc;
         if ((rc = upload(s->bvh_prim_index, bvh.prim_index)) != RT_OK) return rc;
         s->n_bvh_nodes = (int)bvh.nodes.size();
+        for (int k = 0; k < 3; ++k) {
+            s->bvh_root_mn[k] = bvh.root_mn[k];
+            s->bvh_root_mx[k] = bvh.root_mx[k];
+            s->bvh_center[k] = bvh.center[k];
+        }
         // the device table is stored in leaf order, so a leaf is a contiguous run of records
         std::vector<rtdev::Prim> ordered(prims.size());
         for (size_t j = 0; j < bvh.prim_index.size(); ++j) ordered[j] = prims[(size_t)bvh.prim_index[j]];
@@ -605,8 +616,9 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
     if (const char *k = getenv("RT_BVH_LDS")) s->bvh_nodes_in_lds = s->bvh_nodes_in_lds && atoi(k) != 0;
 #endif
     // dynamic LDS of the variant: the BVH node array, or the primitive table of the linear-loop variants
-    const size_t dyn_lds = s->use_bvh ? (s->bvh_nodes_in_lds ? (size_t)s->n_bvh_nodes * sizeof(rtdev::BvhNode) : 0)
-                                      : (size_t)s->n_prims * sizeof(rtdev::Prim) + (s->textured ? (size_t)s->n_textures * sizeof(rtdev::Texture) : 0);
+    const size_t dyn_lds = (s->use_bvh ? (s->bvh_nodes_in_lds ? (size_t)s->n_bvh_nodes * sizeof(rtdev::BvhNode) : 0)
+                                       : (size_t)s->n_prims * sizeof(rtdev::Prim) + (s->textured ? (size_t)s->n_textures * sizeof(rtdev::Texture) : 0)) +
+                           (s->textured && s->n_perlins > 0 && s->perlin_identity ? sizeof(double) * 256 * 3 : 0);
     s->pool_blocks_per_cu = rtdev_pool_blocks_per_cu(s->prims_class, s->textured, s->specular, s->use_bvh, dyn_lds);
 #ifdef RT_DEVELOPER_KNOBS // occupancy experiments
     if (const char *k = getenv("RT_POOL_BLOCKS_PER_CU"))

@@ -57,13 +57,22 @@ void primitive_bounds(const RtPrimitive &p, double mn[3], double mx[3]) {
 
 namespace {
 
+struct Node64 { // the builder's own node: f64 box, links as on the device
+    double mn[3], mx[3];
+    int32_t skip, first, count;
+};
+struct Build64 {
+    std::vector<Node64> nodes;
+    std::vector<int32_t> prim_index;
+};
+
 struct Item {
     double mn[3], mx[3], centroid[3];
     int32_t prim;
 };
 
 // Emits the subtree over items[begin, end) in depth-first order; returns its root index.
-int emit(BvhBuild &out, std::vector<Item> &items, int begin, int end) {
+int emit(Build64 &out, std::vector<Item> &items, int begin, int end) {
     int me = (int)out.nodes.size();
     out.nodes.emplace_back();
     double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
@@ -87,9 +96,8 @@ int emit(BvhBuild &out, std::vector<Item> &items, int begin, int end) {
         leaf = false;
         axis = -1;
     }
-    BvhNode node;
+    Node64 node;
     for (int k = 0; k < 3; ++k) { node.mn[k] = mn[k]; node.mx[k] = mx[k]; }
-    node._pad = 0;
     if (leaf) {
         node.first = (int32_t)out.prim_index.size();
         node.count = n;
@@ -156,10 +164,21 @@ int emit(BvhBuild &out, std::vector<Item> &items, int begin, int end) {
     return me;
 }
 
+// x rounded to float toward -inf / +inf
+float round_down(double x) {
+    float f = (float)x;
+    return (double)f > x ? std::nextafterf(f, -INFINITY) : f;
+}
+float round_up(double x) {
+    float f = (float)x;
+    return (double)f < x ? std::nextafterf(f, INFINITY) : f;
+}
+
 } // namespace
 
 BvhBuild build_bvh(const RtPrimitive *prims, int n_prims) {
     BvhBuild out;
+    for (int k = 0; k < 3; ++k) out.root_mn[k] = out.root_mx[k] = out.center[k] = 0.0;
     if (n_prims <= 0) return out;
     std::vector<Item> items((size_t)n_prims);
     for (int i = 0; i < n_prims; ++i) {
@@ -168,8 +187,35 @@ BvhBuild build_bvh(const RtPrimitive *prims, int n_prims) {
         for (int k = 0; k < 3; ++k) it.centroid[k] = 0.5 * (it.mn[k] + it.mx[k]);
         it.prim = i;
     }
-    out.nodes.reserve((size_t)n_prims);
-    emit(out, items, 0, n_prims);
+    Build64 tree;
+    tree.nodes.reserve((size_t)n_prims);
+    emit(tree, items, 0, n_prims);
+    out.prim_index = tree.prim_index;
+    // Device form: f32 boxes around the root's centre.  A ray is clipped to the root box in f64 before the walk, so
+    // its origin is at most `extent` from the centre and the f32 slab test is off by a few 2^-24 * extent in the
+    // plane positions: the boxes are padded by 2^-20 * extent and rounded outward.
+    const Node64 &root = tree.nodes[0];
+    double extent = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        out.center[k] = 0.5 * (root.mn[k] + root.mx[k]);
+        extent = std::max(extent, 0.5 * (root.mx[k] - root.mn[k]));
+    }
+    const double pad = std::ldexp(extent, -20);
+    for (int k = 0; k < 3; ++k) {
+        out.root_mn[k] = root.mn[k] - pad;
+        out.root_mx[k] = root.mx[k] + pad;
+    }
+    out.nodes.resize(tree.nodes.size());
+    for (size_t i = 0; i < tree.nodes.size(); ++i) {
+        const Node64 &n = tree.nodes[i];
+        BvhNode &q = out.nodes[i];
+        for (int k = 0; k < 3; ++k) {
+            q.mn[k] = round_down(n.mn[k] - out.center[k] - pad);
+            q.mx[k] = round_up(n.mx[k] - out.center[k] + pad);
+        }
+        q.skip = n.skip;
+        q.first_count = n.count > 0 ? (n.first << 3) | n.count : 0;
+    }
     return out;
 }
 

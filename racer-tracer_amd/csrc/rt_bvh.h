@@ -13,8 +13,9 @@
 //     i = 0;  while (i < n) { if (ray hits node i) { test its primitives (leaf); i = i + 1 or skip } else i = skip[i]; }
 //
 // Boxes are the TRUE bounds of the primitives (not rotate_y.rs:66-90's
-// mis-sized ones), inflated by 1e-9 relative so the slab test can never
-// reject a primitive whose own intersection routine accepts the ray.
+// mis-sized ones), inflated so the slab test can never reject a primitive
+// whose own intersection routine accepts the ray; on the device they are
+// single-precision culling boxes around the root's centre (BvhNode).
 #pragma once
 #include <stdint.h>
 #include <vector>
@@ -24,8 +25,10 @@
 namespace rtdev {
 
 struct BvhBuild {
-    std::vector<BvhNode> nodes;
+    std::vector<BvhNode> nodes;      // compact device form (rt_device_types.h)
     std::vector<int32_t> prim_index; // leaves refer to ranges of this list
+    double root_mn[3], root_mx[3];   // root box, f64, padded like the node boxes
+    double center[3];                // the node boxes are relative to this point
 };
 
 // Host-side build over the ABI primitives (wrappers and motion included in the bounds).

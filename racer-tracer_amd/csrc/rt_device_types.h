@@ -70,14 +70,16 @@ struct Perlin { // gradient table only: perm tables are folded into `index`
     int32_t perm_x[256], perm_y[256], perm_z[256];
 };
 
-struct alignas(16) BvhNode { // 64 B; depth-first order with a skip link (rt_bvh.h)
-    double mn[3], mx[3];
-    int32_t skip;   // next node when this subtree is finished or missed (n_nodes = done)
-    int32_t first;  // leaf: first entry in the primitive index list; inner: -1
-    int32_t count;  // leaf: number of primitives (1..4); inner: 0
-    int32_t _pad;
+// 32 B; depth-first order with a skip link (rt_bvh.h).  The box is for CULLING only, so it is kept in single
+// precision: coordinates relative to the root box's centre (TraceArgs.bvh_center), rounded outward and padded by
+// 2^-20 of the scene's extent — more than the f32 slab test of a ray whose origin lies inside the root box can be
+// off by (closest_hit_bvh clips the ray to the root box in f64 first).  Primitives are tested in f64 as everywhere.
+struct alignas(16) BvhNode {
+    float mn[3], mx[3];
+    int32_t skip;         // next node when this subtree is finished or missed (n_nodes = done)
+    int32_t first_count;  // leaf: (first primitive of the leaf << 3) | number of primitives (1..4); inner: 0
 };
-static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+static_assert(sizeof(BvhNode) == 32, "BvhNode must be 32 bytes");
 
 struct Camera { // what get_ray reads (camera.rs:326-337)
     double origin[3], ulc[3], right[3], up[3], horizontal[3], vertical[3];
@@ -117,6 +119,7 @@ struct TraceArgs {
     const Perlin *perlins;
     int32_t n_prims, n_materials, n_textures, n_images, n_perlins;
     int32_t perlin_identity;     // every Perlin's permutation tables are the identity (always so in the reference)
+    int32_t perlin_in_lds;       // the first table's gradients (6 KB) are staged at the end of the dynamic LDS
     int32_t width, height;       // full image
     int32_t samples, max_depth;
     int32_t sample_begin, sample_end; // this launch accumulates samples [begin, end)
@@ -152,6 +155,8 @@ struct TraceArgs {
     int32_t x_origin;
     // BVH (scenes with more primitives than the brute-force loop is good for)
     const BvhNode *bvh_nodes;
+    double bvh_root_mn[3], bvh_root_mx[3]; // the root box in f64 (padded like the node boxes)
+    double bvh_center[3];                  // origin of the node boxes' coordinates
     const int32_t *bvh_prim_index;
     int32_t n_bvh_nodes;
     int32_t bvh_lds_nodes; // == n_bvh_nodes when the node array is staged in dynamic LDS, else 0

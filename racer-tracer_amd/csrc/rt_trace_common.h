@@ -318,31 +318,58 @@ template <int PRIMS>
 __device__ __forceinline__ void closest_hit_bvh(const TraceArgs &A, const BvhNode *nodes, d3 o, d3 d, d3 inv_d,
                                                 double inv_a, double time, double t_min, double &best_t, int &best,
                                                 int &best_aux, unsigned *walk_stats = nullptr) {
+    // CULLING IN SINGLE PRECISION.  The node boxes only decide which primitives get tested (in f64, as everywhere),
+    // so they are f32 boxes around the root's centre, 32 B per node.  The ray is first clipped to the root box in
+    // f64: from there its origin is within the scene's extent E of the centre, the f32 plane distances below are
+    // off by a few 2^-24 E in the plane position — the boxes are padded by 2^-20 E (rt_bvh.cpp) — and by 2^-23
+    // relative in t, for which the interval test carries a 2^-20 relative slack.
+    const RT_CONSTANT TraceArgs *K = kernargs_here();
+    double t0 = 0.0; // ray parameter of the clipped origin
+    {
+        const double ax = (K->bvh_root_mn[0] - o.x) * inv_d.x, bx = (K->bvh_root_mx[0] - o.x) * inv_d.x;
+        const double ay = (K->bvh_root_mn[1] - o.y) * inv_d.y, by = (K->bvh_root_mx[1] - o.y) * inv_d.y;
+        const double az = (K->bvh_root_mn[2] - o.z) * inv_d.z, bz = (K->bvh_root_mx[2] - o.z) * inv_d.z;
+        // fmin/fmax drop NaNs (0 * inf on a slab boundary), which keeps the test conservative
+        const double t_enter = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
+        const double t_exit = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmin(fmax(az, bz), best_t));
+        if (!(fmax(t_enter, t_min) <= t_exit)) return; // misses the scene's bounds
+        if (t_enter > 0.0) t0 = t_enter;
+    }
+    const float ofx = (float)(fma(t0, d.x, o.x) - K->bvh_center[0]), ofy = (float)(fma(t0, d.y, o.y) - K->bvh_center[1]),
+                ofz = (float)(fma(t0, d.z, o.z) - K->bvh_center[2]);
+    const float ivx = (float)inv_d.x, ivy = (float)inv_d.y, ivz = (float)inv_d.z;
+    const float oix = ofx * ivx, oiy = ofy * ivy, oiz = ofz * ivz;
+    const float slack = 0x1p-20f;
+    // the window [t_min, best_t] seen from the clipped origin, rounded outward
+    const float tmin_f = (float)(t_min - t0) - fabsf((float)(t_min - t0)) * slack - 0x1p-126f;
+    auto far_of = [&](double bt) { // upper end of the window
+        const float f = (float)(bt - t0);
+        return f + fabsf(f) * slack;
+    };
+    float best_f = far_of(best_t);
     int i = 0;
     const int n = A.n_bvh_nodes;
-    // slab distances as one fma per plane: (m - o) / d = m * (1/d) - o * (1/d).  Culling only: the boxes are padded by
-    // 1e-9 relative, five orders of magnitude more than this form's rounding differs from the subtract-then-multiply one
-    const d3 oi = mk(o.x * inv_d.x, o.y * inv_d.y, o.z * inv_d.z);
     while (i < n) {
         int count = 0, first = 0;
         while (i < n) { // descend / skip until a leaf is entered
             if (walk_stats) ++walk_stats[0]; // profile build: nodes visited
             const BvhNode *N = &nodes[i];
-            const double ax = fma(N->mn[0], inv_d.x, -oi.x), bx = fma(N->mx[0], inv_d.x, -oi.x);
-            const double ay = fma(N->mn[1], inv_d.y, -oi.y), by = fma(N->mx[1], inv_d.y, -oi.y);
-            const double az = fma(N->mn[2], inv_d.z, -oi.z), bz = fma(N->mx[2], inv_d.z, -oi.z);
-            // fmin/fmax drop NaNs (0 * inf on a slab boundary), which keeps the test conservative
-            const double t_near = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmax(fmin(az, bz), t_min));
-            const double t_far = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmin(fmax(az, bz), best_t));
-            if (t_near <= t_far) {
-                count = N->count;
-                first = N->first;
+            const float ax = fmaf(N->mn[0], ivx, -oix), bx = fmaf(N->mx[0], ivx, -oix);
+            const float ay = fmaf(N->mn[1], ivy, -oiy), by = fmaf(N->mx[1], ivy, -oiy);
+            const float az = fmaf(N->mn[2], ivz, -oiz), bz = fmaf(N->mx[2], ivz, -oiz);
+            const float t_near = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin_f));
+            const float t_far = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best_f));
+            if (t_near <= fmaf(fabsf(t_far), slack, t_far)) {
+                const int fc = N->first_count;
+                count = fc & 7;
+                first = fc >> 3;
                 i = i + 1; // inner: first child; leaf: its skip link is i + 1 as well
                 if (count > 0) break;
             } else {
                 i = N->skip;
             }
         }
+        bool improved = false;
         for (int k = 0; k < count; ++k) { // the leaf's primitives (stored contiguously in leaf order)
             if (walk_stats) ++walk_stats[1]; // profile build: primitives tested
             const int pi = first + k;
@@ -352,8 +379,10 @@ __device__ __forceinline__ void closest_hit_bvh(const TraceArgs &A, const BvhNod
                 best_t = t;
                 best = pi;
                 best_aux = aux;
+                improved = true;
             }
         }
+        if (improved) best_f = far_of(best_t);
     }
 }
 

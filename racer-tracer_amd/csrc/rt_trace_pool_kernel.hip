@@ -51,6 +51,12 @@
 #ifndef RT_OCC_TEX
 #define RT_OCC_TEX 4 // textured spheres-only / rects-only variants: 40 KB of LDS per block still fits four (C4 +3 %)
 #endif
+#ifndef RT_OCC_TEX_BVH
+#define RT_OCC_TEX_BVH 4 // textured BVH variants: 32-byte nodes and no Perlin table in static LDS leave room for four blocks (random scene +20 %)
+#endif
+#ifndef RT_OCC_TEX_ANY
+#define RT_OCC_TEX_ANY 4 // textured linear-loop variants with any primitive kind (emissive.yml 24.5 -> 22.8 ms against three)
+#endif
 #ifndef RT_OCC_SPEC
 #define RT_OCC_SPEC 5
 #endif
@@ -314,40 +320,43 @@ __device__ __forceinline__ double coop_noise_turbulence(bool need, d3 p, int dep
 // BVH: closest hit through the skip-link hierarchy instead of the linear loop
 // (instantiated for PRIMS_ANY only; chosen for scenes with many primitives).
 template <int PRIMS, bool TEXTURED, bool SPECULAR, bool BVH>
-__global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? 3 : RT_OCC_TEX) : ((BVH || PRIMS == PRIMS_ANY) ? 4 : (SPECULAR ? RT_OCC_SPEC : 5))) void k_trace_pool_f64(const TraceArgs A) {
+__global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC_TEX_BVH : RT_OCC_TEX_ANY) : RT_OCC_TEX) : ((BVH || PRIMS == PRIMS_ANY) ? 4 : (SPECULAR ? RT_OCC_SPEC : 5))) void k_trace_pool_f64(const TraceArgs A) {
     // Two batches of camera samples stay ahead of the hand-out, so that it may straddle a batch
     // boundary; the BVH variants keep one (their node array wants the LDS: three resident blocks
     // instead of two on the `random` scene) and a hand-out stops at the end of its batch.
     constexpr int NBUF = BVH ? 1 : 2;
     __shared__ WaveLds<PRIMS == PRIMS_ANY, NBUF> lds_all[4];
+    // Dynamic LDS of a block: [BVH nodes | primitive table + texture table][Perlin gradients]; the host sizes it
+    // (pool_dynamic_lds below) and says what is in it.
+    extern __shared__ __align__(16) unsigned char dyn_lds[];
     // The gradients of the first Perlin table (6 KB) are staged in LDS once per block when the
     // permutation tables are the identity (always, in the reference: noise.rs:121-130): the 56
     // random gradient fetches of a marble lookup then hit LDS instead of the vector memory
-    // path, and the lattice hash needs no table.
+    // path, and the lattice hash needs no table.  Scenes without a Noise texture do not pay the 6 KB.
     struct PerlinGradients {
         double ranvec[256][3];
     };
     static_assert(offsetof(Perlin, ranvec) == 0, "the gradients lead the Perlin record");
-    __shared__ typename std::conditional<TEXTURED, PerlinGradients, int>::type lds_perlin_storage;
     const Perlin *lds_perlin = nullptr;
     if (TEXTURED) {
-        if (A.n_perlins > 0 && A.perlin_identity) {
+        if (A.perlin_in_lds) {
+            const size_t at = BVH ? (size_t)A.bvh_lds_nodes * sizeof(BvhNode)
+                                  : (size_t)A.n_prims * sizeof(Prim) + (size_t)A.n_textures * sizeof(Texture);
             const uint64_t *src = reinterpret_cast<const uint64_t *>(A.perlins);
-            uint64_t *dst = reinterpret_cast<uint64_t *>(&lds_perlin_storage);
+            uint64_t *dst = reinterpret_cast<uint64_t *>(dyn_lds + at);
             for (int i = threadIdx.x; i < (int)(sizeof(PerlinGradients) / 8); i += 256) dst[i] = src[i];
-            lds_perlin = reinterpret_cast<const Perlin *>(&lds_perlin_storage); // only .ranvec is read (IDENTITY path)
+            lds_perlin = reinterpret_cast<const Perlin *>(dyn_lds + at); // only .ranvec is read (IDENTITY path)
         }
         __syncthreads();
     }
-    // BVH nodes are staged in dynamic LDS when they fit (the host sets bvh_lds_nodes and
-    // the launch's dynamic size): a traversal step is a dependent load, and ~100 steps at
+    // BVH nodes are staged in dynamic LDS when they fit (the host sets bvh_lds_nodes):
+    // a traversal step is a dependent load, and ~100 steps at
     // L2 latency with 3-4 waves per SIMD is what bounds the big-scene variants.
-    extern __shared__ __align__(16) unsigned char dyn_lds[];
     const BvhNode *lds_nodes = nullptr;
     if (BVH && A.bvh_lds_nodes > 0) {
         const uint4 *src = reinterpret_cast<const uint4 *>(A.bvh_nodes);
         uint4 *dst = reinterpret_cast<uint4 *>(dyn_lds);
-        for (int i = threadIdx.x; i < A.bvh_lds_nodes * 4; i += 256) dst[i] = src[i];
+        for (int i = threadIdx.x; i < A.bvh_lds_nodes * (int)(sizeof(BvhNode) / 16); i += 256) dst[i] = src[i];
         lds_nodes = reinterpret_cast<const BvhNode *>(dyn_lds);
         __syncthreads();
     }
@@ -834,8 +843,9 @@ namespace {
 // linear closest-hit loop, plus PRIMS_ANY x TEXTURED x SPECULAR with the BVH.
 template <int PRIMS, bool TEXTURED, bool SPECULAR, bool BVH> struct PoolVariant {
     static void launch(const rtdev::TraceArgs &a, unsigned blocks, hipStream_t stream) {
-        const size_t dyn = BVH ? (size_t)a.bvh_lds_nodes * sizeof(rtdev::BvhNode)
-                               : (size_t)a.n_prims * sizeof(rtdev::Prim) + (TEXTURED ? (size_t)a.n_textures * sizeof(rtdev::Texture) : 0);
+        const size_t dyn = (BVH ? (size_t)a.bvh_lds_nodes * sizeof(rtdev::BvhNode)
+                                : (size_t)a.n_prims * sizeof(rtdev::Prim) + (TEXTURED ? (size_t)a.n_textures * sizeof(rtdev::Texture) : 0)) +
+                           (TEXTURED && a.perlin_in_lds ? sizeof(double) * 256 * 3 : 0);
         hipLaunchKernelGGL((rtdev::k_trace_pool_f64<PRIMS, TEXTURED, SPECULAR, BVH>), dim3(blocks), dim3(256), dyn, stream, a);
     }
     static int blocks_per_cu(size_t dyn_lds) {
