@@ -71,7 +71,7 @@ struct RtScene {
     rtapi::DevBuf<int32_t> bvh_prim_index;
     int n_bvh_nodes = 0;
     double bvh_root_mn[3] = {0, 0, 0}, bvh_root_mx[3] = {0, 0, 0}, bvh_center[3] = {0, 0, 0};
-    bool bvh_nodes_in_lds = false; // node array (64 B each) staged in dynamic LDS when <= 32 KiB
+    bool bvh_nodes_in_lds = false; // node array (32 B each) staged in dynamic LDS when <= 32 KiB
 
     // pooled kernel (default): persistent grid = CUs x resident blocks of the variant
     bool use_v1 = false;   // RtSceneOptions.kernel == RT_KERNEL_V1: the lane-per-pixel kernel
