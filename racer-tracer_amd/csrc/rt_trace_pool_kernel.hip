@@ -9,8 +9,9 @@
 //
 // 1. PERSISTENT WAVES + ITEM QUEUE.  The grid is sized to what is resident
 //    (CUs x blocks per CU); every wave pulls items from one atomic counter
-//    until the queue is dry.  An item is a tile x a chunk of its samples, so
-//    the end-of-launch tail is one small item, not one whole tile x all spp.
+//    until the queue is dry.  An item is a tile x a chunk of its samples; the
+//    chunk plan (rt_api.hip: chunk_plan, a function of spp only) has long chunks
+//    first and a taper of short ones last, so a launch ends on small items.
 //
 // 2. LANES ARE NOT PIXELS.  Inside an item the 64 lanes share a pool of
 //    64 x chunk (pixel, sample) paths: whenever lanes have no path in flight a
@@ -40,6 +41,14 @@
 //
 // 5. UNIFORMS ARE RE-READ WHERE THEY ARE USED (kernargs_here): camera and background would
 //    otherwise sit in SGPRs across the path loop and be spilled to VGPR lanes.
+//
+// 6. NO SCALAR SWITCH IN THE CLOSEST-HIT LOOP.  The device table is grouped by kind (plain XY / XZ / YZ
+//    rects, plain spheres, the rest); each group gets one straight-line test with the plane a compile-time
+//    constant.  With a wave-uniform index the `match` on a record's kind was scalar control flow, ~25 SALU
+//    instructions and half a dozen branches around 12 vector instructions per rect.
+//
+// 7. THE ONE EXPENSIVE TEXTURE IS EVALUATED BY THE WHOLE WAVE (coop_noise_turbulence): lanes only note
+//    their Noise lookup while shading; eight lookups per round take eight lanes each, one octave per lane.
 //
 // The launch is VALU-throughput bound (DESIGN.md 4.2 has the counters, the per-region
 // cycle profile of the -DRT_PROFILE_REGIONS build, and the variants that were measured and
