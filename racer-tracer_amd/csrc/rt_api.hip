@@ -410,6 +410,7 @@ void rt_scene_destroy(RtScene *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->stream2) (void)hipStreamSynchronize(s->stream2);
     for (uint8_t *p : s->image_pixels)
         if (p) (void)hipFree(p);
     s->prims.release();
@@ -432,6 +433,7 @@ void rt_scene_destroy(RtScene *s) {
         if (s->pinned[k]) (void)hipHostFree(s->pinned[k]);
     }
     if (s->stream) (void)hipStreamDestroy(s->stream);
+    if (s->stream2) (void)hipStreamDestroy(s->stream2);
     delete s;
 }
 
@@ -627,6 +629,7 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
     RT_HIP(s->segments.alloc(rtdev::RT_STAT_SLOTS)); // rt_device_types.h: RT_STAT_*
     RT_HIP(hipMemset(s->segments.ptr, 0, rtdev::RT_STAT_SLOTS * sizeof(unsigned long long)));
     RT_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    RT_HIP(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
     RT_HIP(hipEventCreate(&s->ev_begin));
     RT_HIP(hipEventCreate(&s->ev_traced));
     RT_HIP(hipEventCreate(&s->ev_resolved));
@@ -754,29 +757,42 @@ int rt_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, RtTil
         bool cancelled = false;
         bool started = false; // the first non-empty window resets the counters and records ev_begin
         int pending = -1;     // column whose copy is in flight
+        // Columns alternate between two streams (one when a cancel flag makes every batch synchronise anyway): the
+        // next column's waves fill the CUs that the previous column's last items leave idle, instead of each of the
+        // launches paying its own ramp and tail.
+        hipStream_t streams[2] = {s->stream, cancel ? s->stream : s->stream2};
+        auto drain = [&] {
+            (void)hipStreamSynchronize(s->stream);
+            (void)hipStreamSynchronize(s->stream2);
+        };
         for (int ws = 0; ws < p->tiles_w && !cancelled; ++ws) {
+            hipStream_t stream = streams[ws & 1];
             Window win;
             win.x0 = window_begin(ws);
             win.width = window_begin(ws + 1) - win.x0;
             win.index = started ? ws : 0;
             win.count = p->tiles_w;
             if (win.width > 0) {
-                rc = enqueue_render(s, camera, p, s->frame.ptr, s->stream, batch, cancel, win);
+                // the counters are reset and ev_begin is recorded by the first window, on ITS stream
+                if (started && stream != s->last_stream) RT_HIP(hipStreamWaitEvent(stream, s->ev_begin, 0));
+                rc = enqueue_render(s, camera, p, s->frame.ptr, stream, batch, cancel, win);
                 started = true;
                 if (rc == RT_ERR_CANCEL_EVENT) {
                     cancelled = true;
                     break;
                 }
                 if (rc != RT_OK) {
-                    (void)hipStreamSynchronize(s->stream);
+                    drain();
                     return rc;
                 }
             }
             const int cx = column_x(ws), cw = column_w(ws);
+            // column ws may begin with pixels of the window before it (windows are cut on the 8-pixel grid)
+            if (ws > 0) RT_HIP(hipStreamWaitEvent(stream, s->ev_column[(ws - 1) & 1], 0));
             RT_HIP(hipMemcpy2DAsync(s->pinned[ws & 1], (size_t)cw * 3 * sizeof(double), s->frame.ptr + (size_t)cx * 3,
                                     (size_t)p->width * 3 * sizeof(double), (size_t)cw * 3 * sizeof(double),
-                                    (size_t)p->height, hipMemcpyDeviceToHost, s->stream));
-            RT_HIP(hipEventRecord(s->ev_column[ws & 1], s->stream));
+                                    (size_t)p->height, hipMemcpyDeviceToHost, stream));
+            RT_HIP(hipEventRecord(s->ev_column[ws & 1], stream));
             if (pending >= 0) { // the previous column is (or soon will be) on the host
                 RT_HIP(hipEventSynchronize(s->ev_column[pending & 1]));
                 if (!emit_column(pending, s->pinned[pending & 1])) cancelled = true;
@@ -784,11 +800,12 @@ int rt_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, RtTil
             pending = ws;
         }
         if (cancelled) { // cpu.rs:55-62: Ok(()), nothing further is written
-            (void)hipStreamSynchronize(s->stream);
+            drain();
             return RT_OK;
         }
         RT_HIP(hipEventSynchronize(s->ev_column[pending & 1]));
         emit_column(pending, s->pinned[pending & 1]);
+        drain(); // both streams are idle when the call returns
         return RT_OK;
     }
 

@@ -85,6 +85,7 @@ struct RtScene {
     rtapi::DevBuf<uint8_t> rgba;  // packed frame of rt_render_frame_rgba8
     rtapi::DevBuf<unsigned long long> segments;
     hipStream_t stream = nullptr; // used by rt_render_frame / rt_render
+    hipStream_t stream2 = nullptr; // rt_render: tile columns alternate between the two, so a column's ramp-up fills the CUs its predecessor's tail leaves idle
     hipEvent_t ev_begin = nullptr, ev_traced = nullptr, ev_resolved = nullptr;
     // rt_render's progressive delivery: two pinned column buffers [height][column width][3]
     // and the events that say a column's copy has landed
