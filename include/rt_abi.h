@@ -331,10 +331,12 @@ int rt_render_frame_device(RtScene *scene, const RtCamera *camera,
  * and copied while the callbacks of the previous column run, so tiles arrive
  * during the render as the reference's do (cpu.rs:64-70); their pixels are
  * bit-identical to rt_render_frame's.  `cancel` (may be NULL) is polled like
- * `do_cancel` (renderer.rs:25-30) before every launch and every callback: once
- * it is non-zero the call returns RT_OK and emits nothing further; tiles
- * delivered before stay delivered (cpu.rs:55-62).  If it is already set on
- * entry the call returns RT_ERR_CANCEL_EVENT (cpu.rs:82-85).
+ * `do_cancel` (renderer.rs:25-30) before every launch and every callback and
+ * while the call waits for the GPU: once it is non-zero the waves in flight
+ * stop at their next work item, the call returns RT_OK and emits nothing
+ * further; tiles delivered before stay delivered (cpu.rs:55-62).  Passing a
+ * flag costs nothing while it stays zero.  If it is already set on entry the
+ * call returns RT_ERR_CANCEL_EVENT (cpu.rs:82-85).
  * params->strip_count > 1 is refused (RT_ERR_INVALID_ARGUMENT): tiles are finished pieces of the
  * frame.  rt_scene_last_stats after this call: kernel_ms spans all columns. */
 int rt_render(RtScene *scene, const RtCamera *camera, const RtRenderParams *params,

@@ -10,6 +10,8 @@
 #include <new>
 #include <string>
 #include <vector>
+#include <thread>
+#include <chrono>
 #include "rt_bvh.h"
 #include "rt_scene.h"
 
@@ -336,6 +338,8 @@ int rtapi::enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderPara
             a.n_chunks = l.n_chunks;
             a.chunk_base = l.first_chunk;
             a.n_items = (uint32_t)a.n_chunks * (uint32_t)a.n_tiles;
+            if ((uint64_t)a.n_chunks * (uint64_t)a.n_tiles >= 0x40000000ull) // the item counter's top bit is the cancel poison
+                return fail(RT_ERR_UNSUPPORTED, "more than 2^30 work items in one launch");
             a.queue = s->queue.ptr + (size_t)win.index * (size_t)n_batches + launches;
             unsigned blocks = (unsigned)(s->num_cus * s->pool_blocks_per_cu);
             unsigned needed = (a.n_items + 3) / 4;
@@ -343,7 +347,6 @@ int rtapi::enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderPara
             RT_HIP(rtdev_launch_trace_pool(&a, s->prims_class, s->textured, s->specular, s->use_bvh, blocks, stream));
             chunks_done += a.n_chunks;
             ++launches;
-            if (cancel) RT_HIP(hipStreamSynchronize(stream)); // so the next poll is meaningful
         }
         RT_HIP(hipEventRecord(s->ev_traced, stream));
         RT_HIP(rtdev_launch_resolve_chunks(s->partial.ptr, out_device, p->width, p->height, chunks_done, a.strip_rows,
@@ -359,6 +362,44 @@ int rtapi::enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderPara
     return RT_OK;
 }
 using rtapi::enqueue_render;
+
+namespace {
+// Block until `ev` has happened; with a cancel flag, poll it meanwhile and give up
+// (RT_ERR_CANCEL_EVENT) as soon as it is set.
+int wait_event(hipEvent_t ev, const volatile int *cancel) {
+    if (!cancel) {
+        RT_HIP(hipEventSynchronize(ev));
+        return RT_OK;
+    }
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return RT_OK;
+        if (e != hipErrorNotReady) return fail(RT_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
+        (void)hipGetLastError(); // hipErrorNotReady is sticky in hipGetLastError otherwise
+        if (*cancel) return RT_ERR_CANCEL_EVENT;
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+
+// Ends the pool launches of the current call early: every item counter of the call becomes 2^31
+// (enqueue_render keeps a launch below 2^30 items, so no count of further hand-outs wraps it).
+// The copy runs on its own stream, beside the kernels it stops.
+int poison_queue(RtScene *s) {
+    const size_t slots = s->queue.count;
+    if (slots == 0) return RT_OK;
+    if (s->poison_count < slots) {
+        if (s->poison) (void)hipHostFree(s->poison);
+        s->poison = nullptr;
+        s->poison_count = 0;
+        RT_HIP(hipHostMalloc((void **)&s->poison, slots * sizeof(unsigned int), hipHostMallocDefault));
+        s->poison_count = slots;
+        for (size_t i = 0; i < slots; ++i) s->poison[i] = 0x80000000u;
+    }
+    RT_HIP(hipMemcpyAsync(s->queue.ptr, s->poison, slots * sizeof(unsigned int), hipMemcpyHostToDevice, s->stream_ctl));
+    RT_HIP(hipStreamSynchronize(s->stream_ctl));
+    return RT_OK;
+}
+} // namespace
 
 extern "C" {
 
@@ -434,6 +475,8 @@ void rt_scene_destroy(RtScene *s) {
     }
     if (s->stream) (void)hipStreamDestroy(s->stream);
     if (s->stream2) (void)hipStreamDestroy(s->stream2);
+    if (s->stream_ctl) (void)hipStreamDestroy(s->stream_ctl);
+    if (s->poison) (void)hipHostFree(s->poison);
     delete s;
 }
 
@@ -634,6 +677,7 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
     RT_HIP(hipEventCreate(&s->ev_traced));
     RT_HIP(hipEventCreate(&s->ev_resolved));
     for (int k = 0; k < 2; ++k) RT_HIP(hipEventCreateWithFlags(&s->ev_column[k], hipEventDisableTiming));
+    RT_HIP(hipStreamCreateWithFlags(&s->stream_ctl, hipStreamNonBlocking));
     guard.s = nullptr;
     *out = s;
     return RT_OK;
@@ -718,9 +762,19 @@ int rt_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, RtTil
     // then the callbacks of column k-1 run on this thread while the GPU works on column k.
     // Every pixel's value is independent of the window it was traced in (the RNG is
     // addressed by the global pixel index, the chunk boundaries depend on spp only), so
-    // the tiles are bit-identical to rt_render_frame's.  The cancel flag is polled before
-    // every launch and every callback; tiles delivered before it rose stay delivered, like
-    // the reference's tiles that finished before the cancel (cpu.rs:55-62).
+    // the tiles are bit-identical to rt_render_frame's.
+    //
+    // CANCEL.  The reference polls `do_cancel` per tile row (cpu.rs:55).  Here the caller's
+    // flag is polled by this thread before every launch and every callback and WHILE it
+    // waits for a column.  When it rises, poison_queue() overwrites the item counters of
+    // this call's launches (running or still queued) with 2^31 from a third stream: every
+    // wave's next hand-out then reads "no items left", so the GPU drains within one item's
+    // time.  The kernels know nothing of it, no launch is split and nothing synchronises
+    // for the flag's sake: a render with a flag costs what one without costs.  (A flag in
+    // mapped host memory that the waves read themselves was measured first: reads of it
+    // cross PCIe one by one, +17 ms on C3's 100 even at one read per 64 items.)  Tiles
+    // delivered before the flag rose stay delivered, like the reference's tiles that
+    // finished before the cancel (cpu.rs:55-62).
     const bool progressive = !s->use_v1 && p->scale <= 1 && p->tiles_w > 1 && width_step > 0;
     if (progressive) {
         int widest = 0;
@@ -734,15 +788,6 @@ int rt_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, RtTil
                 RT_HIP(hipHostMalloc((void **)&s->pinned[k], col_doubles * sizeof(double), hipHostMallocDefault));
                 s->pinned_count[k] = col_doubles;
             }
-        // with a cancel flag every column is traced in sample batches (about 32 launches per
-        // frame, at least 16 samples each), so a rising flag stops the GPU within one batch
-        int batch = 0;
-        if (cancel) {
-            const int per_column = 32 / p->tiles_w > 0 ? 32 / p->tiles_w : 1;
-            batch = (p->samples + per_column - 1) / per_column;
-            if (batch < 16) batch = 16;
-            if (batch > p->samples) batch = p->samples;
-        }
         // A pixel's sum depends on the order its samples meet in LDS, i.e. on which 8x8
         // item tile it sits in.  So the GPU windows are cut on the whole-frame tile grid:
         // window k = [up8(x_k), up8(x_k+1)) (first from 0, last to the image edge) holds
@@ -757,10 +802,9 @@ int rt_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, RtTil
         bool cancelled = false;
         bool started = false; // the first non-empty window resets the counters and records ev_begin
         int pending = -1;     // column whose copy is in flight
-        // Columns alternate between two streams (one when a cancel flag makes every batch synchronise anyway): the
-        // next column's waves fill the CUs that the previous column's last items leave idle, instead of each of the
-        // launches paying its own ramp and tail.
-        hipStream_t streams[2] = {s->stream, cancel ? s->stream : s->stream2};
+        // Columns alternate between two streams: the next column's waves fill the CUs that the previous column's last
+        // items leave idle, instead of each of the launches paying its own ramp and tail.
+        hipStream_t streams[2] = {s->stream, s->stream2};
         auto drain = [&] {
             (void)hipStreamSynchronize(s->stream);
             (void)hipStreamSynchronize(s->stream2);
@@ -775,7 +819,7 @@ int rt_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, RtTil
             if (win.width > 0) {
                 // the counters are reset and ev_begin is recorded by the first window, on ITS stream
                 if (started && stream != s->last_stream) RT_HIP(hipStreamWaitEvent(stream, s->ev_begin, 0));
-                rc = enqueue_render(s, camera, p, s->frame.ptr, stream, batch, cancel, win);
+                rc = enqueue_render(s, camera, p, s->frame.ptr, stream, 0, cancel, win);
                 started = true;
                 if (rc == RT_ERR_CANCEL_EVENT) {
                     cancelled = true;
@@ -794,34 +838,47 @@ int rt_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, RtTil
                                     (size_t)p->height, hipMemcpyDeviceToHost, stream));
             RT_HIP(hipEventRecord(s->ev_column[ws & 1], stream));
             if (pending >= 0) { // the previous column is (or soon will be) on the host
-                RT_HIP(hipEventSynchronize(s->ev_column[pending & 1]));
-                if (!emit_column(pending, s->pinned[pending & 1])) cancelled = true;
+                rc = wait_event(s->ev_column[pending & 1], cancel);
+                if (rc == RT_ERR_CANCEL_EVENT || (rc == RT_OK && !emit_column(pending, s->pinned[pending & 1]))) {
+                    cancelled = true;
+                    break;
+                }
+                if (rc != RT_OK) {
+                    drain();
+                    return rc;
+                }
             }
             pending = ws;
         }
-        if (cancelled) { // cpu.rs:55-62: Ok(()), nothing further is written
-            drain();
-            return RT_OK;
+        if (!cancelled) {
+            rc = wait_event(s->ev_column[pending & 1], cancel);
+            if (rc == RT_OK) emit_column(pending, s->pinned[pending & 1]);
+            cancelled = rc == RT_ERR_CANCEL_EVENT;
         }
-        RT_HIP(hipEventSynchronize(s->ev_column[pending & 1]));
-        emit_column(pending, s->pinned[pending & 1]);
+        if (cancelled) { // cpu.rs:55-62: Ok(()), nothing further is written
+            rc = poison_queue(s); // the waves in flight stop at their next item
+        }
         drain(); // both streams are idle when the call returns
-        return RT_OK;
+        return rc;
     }
 
     // Whole-frame path (preview scale, a single tile column, the v1 kernel): the
-    // tiles are cut from the finished frame.  With a cancel flag, trace in batches so the
-    // flag is polled about as often as the reference polls it per tile row (cpu.rs:55).
+    // tiles are cut from the finished frame.  The pool kernel's waves watch the flag
+    // themselves (above); the v1 kernel is traced in sample batches with a
+    // synchronisation after each, so that its flag is polled about as often as the
+    // reference polls it per tile row (cpu.rs:55).
     int batch = 0;
-    if (cancel) { // at most 32 launches, at least 16 samples each
+    if (cancel && s->use_v1) { // at most 32 launches, at least 16 samples each
         batch = (p->samples + 31) / 32;
         if (batch < 16) batch = 16;
         if (batch > p->samples) batch = p->samples;
     }
     rc = enqueue_render(s, camera, p, s->frame.ptr, s->stream, batch, cancel);
+    if (rc == RT_OK) rc = wait_event(s->ev_resolved, cancel);
     if (rc == RT_ERR_CANCEL_EVENT) { // cpu.rs:55-62: return Ok, no tile written
+        rc = s->use_v1 ? RT_OK : poison_queue(s);
         (void)hipStreamSynchronize(s->stream);
-        return RT_OK;
+        return rc;
     }
     if (rc != RT_OK) return rc;
     RT_HIP(hipStreamSynchronize(s->stream));

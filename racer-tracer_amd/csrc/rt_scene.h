@@ -92,6 +92,11 @@ struct RtScene {
     double *pinned[2] = {nullptr, nullptr};
     size_t pinned_count[2] = {0, 0};
     hipEvent_t ev_column[2] = {nullptr, nullptr};
+    // rt_render's cancel: a pinned array of poisoned item counters and the stream that copies it over the
+    // launches' counters (rt_api.hip: poison_queue)
+    unsigned int *poison = nullptr;
+    size_t poison_count = 0;
+    hipStream_t stream_ctl = nullptr;
     hipStream_t last_stream = nullptr;
     bool has_stats = false;
     int last_launches = 0;

@@ -15,7 +15,8 @@ abi = importlib.import_module("racer-tracer_amd.abi")
 
 session = host.Session(os.path.join(ROOT, "scenes", "config_c3.yml"), scene=os.path.join(ROOT, "scenes", "cornell_box.yml"))
 p = session.params
-scene = rt.Scene(session, device=0)
+library = rt.load_library(os.environ["RT_LIB"]) if os.environ.get("RT_LIB") else None  # e.g. the dev build
+scene = rt.Scene(session, device=0, library=library)
 scene.render_frame(session.camera, p)
 t0 = time.time()
 scene.render_frame(session.camera, p)
@@ -28,10 +29,10 @@ def on_tile(_user, rgb, r, c, w, h):
 
 
 cb = abi.RtTileCallback(on_tile)
-for label, cancel in (("no cancel flag", None), ("with cancel flag", C.pointer(C.c_int(0)))):
+for label, cancel in (("no cancel flag", None), ("with cancel flag", C.pointer(C.c_int(0)))) * 2:
     del arrivals[:]
     t0 = time.time()
-    rc = rt.lib().rt_render(scene._h, C.byref(session.camera), C.byref(p), cb, None, cancel)
+    rc = scene._lib.rt_render(scene._h, C.byref(session.camera), C.byref(p), cb, None, cancel)
     t_tiles = time.time() - t0
     st = scene.last_stats()
     cols = sorted({c for _, _, c in arrivals})
