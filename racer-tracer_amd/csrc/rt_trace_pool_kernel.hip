@@ -113,7 +113,11 @@ namespace rtdev {
     }
 #else
 #define RT_REGION_DECL
+#ifdef RT_ISA_MARKERS // `make isa`: the region boundaries as comments in the assembly listing (tools/isa_regions.py)
+#define RT_REGION(k) asm volatile("; ==== end of region " #k);
+#else
 #define RT_REGION(k)
+#endif
 #define RT_LANES(n, tail)
 #define RT_REGION_FLUSH
 #endif
@@ -152,6 +156,7 @@ template <bool HAS_TIME, int NBUF> struct WaveLds {
     double sum[64][3];  // per-pixel radiance sums of the current item
     SamplerScratch scratch; // cooperative sampler requests / Noise lookups
     int pix_of[64];     // pool slot -> lane-order pixel index, for tiles cut by the image edge
+    uint32_t pixel_id[64]; // lane-order pixel -> index in the image (the RNG address of its paths)
     // Camera samples of the pool entries, drawn 64 entries at a time by the WHOLE wave
     // (prepare_batch below): entry w sits in slot w & 63 of buffer (w >> 6) & (NBUF - 1).
     double v[NBUF][64];        // (py + jv) / (H - 1)                      cpu.rs:39-40
@@ -447,6 +452,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
             L.sum[lane][1] = 0.0;
             L.sum[lane][2] = 0.0;
             if (my_valid) L.pix_of[lane_rank(valid_mask)] = lane;
+            L.pixel_id[lane] = my_pixel;
         }
         const uint32_t total = (uint32_t)n_valid * (uint32_t)n_smp; // paths in this item's pool
         uint32_t next = 0;
@@ -512,7 +518,9 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
         bool waiting = false;
         uint32_t cand_base = 0;   // first untested candidate of the open request
         bool is_lambert = false;  // material of the open hit (else Metal)
-        d3 hit_point = o, hit_normal = o, albedo = o;
+        // the open hit: its point takes the ray origin's place (`o` is dead once the hit record exists) and its
+        // attenuation goes into T at once, so neither is carried as extra state while the lane waits
+        d3 hit_normal = o;
         double fuzz = 0.0;
 
         for (;;) {
@@ -527,8 +535,17 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                 const uint32_t ready = NBUF == 2 ? total : min(total, batches_done << 6);
                 next = min(next + (uint32_t)__popcll(idle), ready);
                 if (!alive && w < ready) { // cpu.rs:39-40 + camera.rs:326-337
-                    int py;
-                    entry_of(w, pix, py, rng.pixel, rng.sample);
+                    // entry_of(w) without the pixel arithmetic: the hand-out runs with a third of the lanes
+                    int s_off;
+                    if (n_valid == 64) {
+                        pix = (int)(w & 63u);
+                        s_off = (int)(w >> 6);
+                    } else {
+                        s_off = (int)(w / (uint32_t)n_valid);
+                        pix = L.pix_of[w - (uint32_t)s_off * (uint32_t)n_valid];
+                    }
+                    rng.pixel = L.pixel_id[pix];
+                    rng.sample = (uint32_t)(smp0 + s_off);
                     const RT_CONSTANT TraceArgs *K = kernargs_here();
                     const int buf = (int)((w >> 6) & (uint32_t)(NBUF - 1)), slot = (int)(w & 63u);
                     const double v = L.v[buf][slot];
@@ -676,17 +693,17 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                         if (kind == RT_MAT_DIFFUSE_LIGHT) { // diffuse_light.rs:25-37
                             contrib = T * tex;
                             ended = true;
-                            if (TEXTURED) hit_point = h.point; // a Noise light is finished below
+                            if (TEXTURED) o = h.point; // a Noise light is finished below
                         } else if (kind == RT_MAT_LAMBERTIAN) { // lambertian.rs:26-38 (direction below)
-                            albedo = tex;
-                            hit_point = h.point;
+                            if (!TEXTURED || noise_tex < 0) T = T * tex; // a Noise attenuation arrives below
+                            o = h.point;
                             hit_normal = h.normal;
                             is_lambert = true;
                             waiting = true;
                             cand_base = 0;
                         } else if (SPECULAR && kind == RT_MAT_METAL) { // metal.rs:26-43 (fuzz below)
-                            albedo = tex;
-                            hit_point = h.point;
+                            if (!TEXTURED || noise_tex < 0) T = T * tex; // (an absorbed reflection ends with contrib 0: T is dead then)
+                            o = h.point;
                             hit_normal = h.normal;
                             fuzz = M.fuzz;
                             is_lambert = false;
@@ -733,12 +750,12 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                 const bool lookup = noise_tex >= 0;
                 if (__ballot(lookup) != 0) {
                     const Texture *tt = BVH ? A.textures : lds_textures;
-                    const double turb = coop_noise_turbulence(lookup, hit_point, lookup ? tt[noise_tex].depth : 0,
+                    const double turb = coop_noise_turbulence(lookup, o, lookup ? tt[noise_tex].depth : 0,
                                                               lookup ? tt[noise_tex].perlin : 0, A, lds_perlin, lane, L.scratch.noise);
                     if (lookup) {
-                        const d3 tex = noise_colour(tt[noise_tex], hit_point, turb);
+                        const d3 tex = noise_colour(tt[noise_tex], o, turb);
                         if (ended) contrib = T * tex; // DiffuseLight: the only material that ends on a textured hit
-                        else albedo = tex;            // Lambertian / Metal attenuation
+                        else T = T * tex;             // Lambertian / Metal attenuation
                     }
                 }
             }
@@ -755,8 +772,6 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                 if (is_lambert) { // lambertian.rs:27-33
                     d3 dir = hit_normal + unit_fast(sph);
                     if (fabs(dir.x) < 1e-8 && fabs(dir.y) < 1e-8 && fabs(dir.z) < 1e-8) dir = hit_normal;
-                    T = T * albedo;
-                    o = hit_point;
                     d = dir;
                     scattered = true;
                 } else if (SPECULAR) { // metal.rs:30-42
@@ -767,8 +782,6 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                         contrib = mk(0.0, 0.0, 0.0);
                         ended = true;
                     } else {
-                        T = T * albedo;
-                        o = hit_point;
                         d = dir;
                         scattered = true;
                     }
