@@ -569,7 +569,8 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
             if (__ballot(alive) == 0) break; // pool dry and nothing in flight
 
             // ---- one ray_color level for every lane with a path
-            d3 contrib = mk(0.0, 0.0, 0.0); // what the path adds to its pixel if it ends here
+            // A path that ends here adds its throughput T (times what it ran into) to its pixel: T is dead
+            // afterwards, so the product is formed in place.
             bool ended = false;
             bool scattered = false;  // the path got a new ray this iteration (depth check below)
             bool finish = false;     // Lambertian / Metal hit whose direction can be completed now
@@ -577,7 +578,6 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
             RT_LANES(__popcll(__ballot(alive && !waiting)), next >= total);
             if (alive && !waiting) {
                 if (A.max_depth <= 0) { // renderer.rs:48-55 with max_depth 0
-                    contrib = T;
                     ended = true;
                 } else {
                     ++n_segments;
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                             const double t = 0.5 * (unit_fast(d).y + 1.0);
                             bgc = (1.0 - t) * bgc + t * ld3(K->bg.bottom);
                         }
-                        contrib = T * bgc;
+                        T = T * bgc;
                         ended = true;
                     } else {
                         const Prim &P = BVH ? A.prims[best] : lds_prims[best];
@@ -690,19 +690,18 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                             else tex = texture_value_deferred(A, BVH ? A.textures : lds_textures, M.texture, h.u, h.v, h.point, noise_tex);
                         }
                         RT_REGION(9); // texture, step 1
+                        // emission (the path ends) or attenuation, one copy for all three; a Noise colour arrives below
+                        if (kind != RT_MAT_DIELECTRIC && (!TEXTURED || noise_tex < 0)) T = T * tex;
                         if (kind == RT_MAT_DIFFUSE_LIGHT) { // diffuse_light.rs:25-37
-                            contrib = T * tex;
                             ended = true;
                             if (TEXTURED) o = h.point; // a Noise light is finished below
                         } else if (kind == RT_MAT_LAMBERTIAN) { // lambertian.rs:26-38 (direction below)
-                            if (!TEXTURED || noise_tex < 0) T = T * tex; // a Noise attenuation arrives below
                             o = h.point;
-                            hit_normal = h.normal;
+                            d = h.normal; // the incoming direction is dead: lambertian.rs:27 starts from the normal
                             is_lambert = true;
                             waiting = true;
                             cand_base = 0;
                         } else if (SPECULAR && kind == RT_MAT_METAL) { // metal.rs:26-43 (fuzz below)
-                            if (!TEXTURED || noise_tex < 0) T = T * tex; // (an absorbed reflection ends with contrib 0: T is dead then)
                             o = h.point;
                             hit_normal = h.normal;
                             fuzz = M.fuzz;
@@ -733,6 +732,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                             o = h.point;
                             scattered = true;
                         } else { // unreachable: the host picks SPECULAR whenever such a material exists
+                            T = mk(0.0, 0.0, 0.0);
                             ended = true;
                         }
                     }
@@ -754,8 +754,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                                                               lookup ? tt[noise_tex].perlin : 0, A, lds_perlin, lane, L.scratch.noise);
                     if (lookup) {
                         const d3 tex = noise_colour(tt[noise_tex], o, turb);
-                        if (ended) contrib = T * tex; // DiffuseLight: the only material that ends on a textured hit
-                        else T = T * tex;             // Lambertian / Metal attenuation
+                        T = T * tex; // DiffuseLight's emission (the path has ended) or Lambertian / Metal attenuation
                     }
                 }
             }
@@ -770,16 +769,15 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
             RT_REGION(5); // sampler
             if (finish) {
                 if (is_lambert) { // lambertian.rs:27-33
-                    d3 dir = hit_normal + unit_fast(sph);
-                    if (fabs(dir.x) < 1e-8 && fabs(dir.y) < 1e-8 && fabs(dir.z) < 1e-8) dir = hit_normal;
-                    d = dir;
+                    const d3 dir = d + unit_fast(sph); // d holds the normal since the hit
+                    if (!(fabs(dir.x) < 1e-8 && fabs(dir.y) < 1e-8 && fabs(dir.z) < 1e-8)) d = dir;
                     scattered = true;
                 } else if (SPECULAR) { // metal.rs:30-42
                     const d3 ud = unit_fast(d);
                     d3 dir = ud - (2.0 * dot(ud, hit_normal)) * hit_normal;
                     if (fuzz != 0.0) dir = dir + fuzz * sph;
                     if (dot(dir, hit_normal) < 0.0) {
-                        contrib = mk(0.0, 0.0, 0.0);
+                        T = mk(0.0, 0.0, 0.0);
                         ended = true;
                     } else {
                         d = dir;
@@ -788,14 +786,11 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                 }
             }
             // renderer.rs:48-55: the recursion's next level has depth 0 -> white
-            if (scattered && (int)++seg >= A.max_depth) {
-                contrib = T;
-                ended = true;
-            }
+            if (scattered && (int)++seg >= A.max_depth) ended = true;
             if (alive && ended) { // vec3.rs:38-42 Color::add into the pixel's sum
-                atomicAdd(&L.sum[pix][0], contrib.x);
-                atomicAdd(&L.sum[pix][1], contrib.y);
-                atomicAdd(&L.sum[pix][2], contrib.z);
+                atomicAdd(&L.sum[pix][0], T.x);
+                atomicAdd(&L.sum[pix][1], T.y);
+                atomicAdd(&L.sum[pix][2], T.z);
                 alive = false;
             }
             RT_REGION(6); // scatter + accumulate
