@@ -156,7 +156,6 @@ template <bool HAS_TIME, int NBUF> struct WaveLds {
     double sum[64][3];  // per-pixel radiance sums of the current item
     SamplerScratch scratch; // cooperative sampler requests / Noise lookups
     int pix_of[64];     // pool slot -> lane-order pixel index, for tiles cut by the image edge
-    uint32_t pixel_id[64]; // lane-order pixel -> index in the image (the RNG address of its paths)
     // Camera samples of the pool entries, drawn 64 entries at a time by the WHOLE wave
     // (prepare_batch below): entry w sits in slot w & 63 of buffer (w >> 6) & (NBUF - 1).
     double v[NBUF][64];        // (py + jv) / (H - 1)                      cpu.rs:39-40
@@ -452,7 +451,6 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
             L.sum[lane][1] = 0.0;
             L.sum[lane][2] = 0.0;
             if (my_valid) L.pix_of[lane_rank(valid_mask)] = lane;
-            L.pixel_id[lane] = my_pixel;
         }
         const uint32_t total = (uint32_t)n_valid * (uint32_t)n_smp; // paths in this item's pool
         uint32_t next = 0;
@@ -534,17 +532,21 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                 // entries whose camera samples are in LDS: all of them with two buffers, the current batch with one
                 const uint32_t ready = NBUF == 2 ? total : min(total, batches_done << 6);
                 next = min(next + (uint32_t)__popcll(idle), ready);
+                // entry_of(w) without the pixel arithmetic: lane p of the wave holds pixel p's index in the image
+                // (my_pixel), so the entry's comes by a lane shuffle — which every lane has to take part in, hence
+                // out here (the lanes that have a path compute an entry nobody reads)
+                int s_off, pix_new;
+                if (n_valid == 64) {
+                    pix_new = (int)(w & 63u);
+                    s_off = (int)(w >> 6);
+                } else {
+                    s_off = (int)(w / (uint32_t)n_valid);
+                    pix_new = L.pix_of[w - (uint32_t)s_off * (uint32_t)n_valid];
+                }
+                const uint32_t pixel_new = (uint32_t)__shfl((int)my_pixel, pix_new, 64);
                 if (!alive && w < ready) { // cpu.rs:39-40 + camera.rs:326-337
-                    // entry_of(w) without the pixel arithmetic: the hand-out runs with a third of the lanes
-                    int s_off;
-                    if (n_valid == 64) {
-                        pix = (int)(w & 63u);
-                        s_off = (int)(w >> 6);
-                    } else {
-                        s_off = (int)(w / (uint32_t)n_valid);
-                        pix = L.pix_of[w - (uint32_t)s_off * (uint32_t)n_valid];
-                    }
-                    rng.pixel = L.pixel_id[pix];
+                    pix = pix_new;
+                    rng.pixel = pixel_new;
                     rng.sample = (uint32_t)(smp0 + s_off);
                     const RT_CONSTANT TraceArgs *K = kernargs_here();
                     const int buf = (int)((w >> 6) & (uint32_t)(NBUF - 1)), slot = (int)(w & 63u);
