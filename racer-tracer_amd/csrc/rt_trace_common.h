@@ -71,7 +71,9 @@ __device__ __forceinline__ double rcp_f64(double x) {
     const double r0 = __builtin_amdgcn_rcp(x);
     double r = fma(r0, fma(-x, r0, 1.0), r0);
     r = fma(r, fma(-x, r, 1.0), r);
-    return __builtin_isfinite(r) ? r : r0; // x = 0 or inf: keep the hardware's inf / 0 like a true division
+    // x = 0 or inf turns the refinement into NaN: v_div_fixup_f64 puts the true quotient's inf / 0 back (one
+    // instruction; it hands every other quotient through unchanged)
+    return __builtin_amdgcn_div_fixup(r, x, 1.0);
 }
 __device__ __forceinline__ double rsqrt_f64(double x) {
 #ifdef RT_EXACT_DIV
@@ -93,13 +95,15 @@ __device__ __forceinline__ double sqrt_fast(double x) {
 #ifdef RT_EXACT_DIV
     return sqrt(x);
 #endif
-    const double y = __builtin_amdgcn_rsq(x);
+    // rsq(0) = inf would turn the products below into NaN; with the seed taken at max(x, 2^-1000) every product
+    // of x = 0 is an exact 0 (one v_max_f64 instead of a compare and two selects; arguments in (0, 2^-1000),
+    // 150 orders of magnitude below any discriminant this kernel forms, would come out wrong)
+    const double y = __builtin_amdgcn_rsq(fmax(x, 0x1p-1000));
     double g = x * y, h = 0.5 * y;
     const double r = fma(-h, g, 0.5);
     g = fma(g, r, g);
     h = fma(h, r, h);
-    g = fma(fma(-g, g, x), h, g);
-    return x == 0.0 ? 0.0 : g; // rsq(0) = inf
+    return fma(fma(-g, g, x), h, g);
 }
 // vec3.rs:79-85 unit_vector with one reciprocal square root instead of a
 // square root and three divisions
