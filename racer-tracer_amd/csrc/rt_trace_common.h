@@ -201,6 +201,24 @@ __device__ __forceinline__ void set_face_normal(Hit &h, d3 dir, d3 outward) { //
     h.normal = h.front ? outward : -outward;
 }
 
+// The same for the rects' outward normal +e_axis (xy_rect.rs:43-45 and its siblings): dot(dir, e_axis) is
+// dir[axis] itself and a hit implies dir[axis] != 0, so the normal is e_axis with the opposite of that sign —
+// three sign-bit operations and three selects instead of a dot product, a compare and six selects.  (The zero
+// components are +0 on either face; the reference's negated (0, 0, 1) has -0 there, which no sum or product
+// downstream can tell apart unless its other operand is an exact zero too.)
+__device__ __forceinline__ void set_face_normal_axis(Hit &h, d3 dir, int axis) {
+#ifdef RT_EXACT_DIV
+    set_face_normal(h, dir, mk(axis == 0 ? 1.0 : 0.0, axis == 1 ? 1.0 : 0.0, axis == 2 ? 1.0 : 0.0));
+#else
+    auto against = [](double dk) { // +1.0 for dk < 0, -1.0 for dk > 0
+        const uint32_t hi = 0xBFF00000u ^ ((uint32_t)((unsigned long long)__double_as_longlong(dk) >> 32) & 0x80000000u);
+        return __longlong_as_double((long long)((unsigned long long)hi << 32));
+    };
+    h.normal = mk(axis == 0 ? against(dir.x) : 0.0, axis == 1 ? against(dir.y) : 0.0, axis == 2 ? against(dir.z) : 0.0);
+    h.front = h.normal.x + h.normal.y + h.normal.z > 0.0; // only Dialectric reads it
+#endif
+}
+
 __device__ __forceinline__ d3 rot_fwd(d3 a, double s, double c) { // rotate_y.rs:42-46
     return mk(c * a.x - s * a.z, a.y, s * a.x + c * a.z);
 }
@@ -454,7 +472,7 @@ __device__ __forceinline__ Hit prim_hit_record(const Prim &P, d3 o, d3 d, double
             h.u = (comp(h.point, ia) - a0) / (a1 - a0);
             h.v = (comp(h.point, ib) - b0) / (b1 - b0);
         }
-        set_face_normal(h, dd, mk(axis == 0 ? 1.0 : 0.0, axis == 1 ? 1.0 : 0.0, axis == 2 ? 1.0 : 0.0));
+        set_face_normal_axis(h, dd, axis);
     }
     if (flags & RT_PRIM_HAS_ROTATE_Y) { // rotate_y.rs:52-63 (face test vs the rotated ray)
         h.point = rot_back(h.point, P.rot_sin, P.rot_cos);

@@ -686,18 +686,20 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
 #endif
                         // Texture::value once for every material that has one (light, Lambertian, Metal):
                         // one copy of the texture code, shared by the lanes of all three
-                        d3 tex = mk(0.0, 0.0, 0.0);
-                        if (kind != RT_MAT_DIELECTRIC) {
+                        // (variants without SPECULAR hold lights and Lambertians only: the host picks SPECULAR
+                        // whenever a Metal or Dialectric exists)
+                        if (!SPECULAR || kind != RT_MAT_DIELECTRIC) {
+                            d3 tex;
                             if (!TEXTURED || M.tex_kind == RT_TEX_SOLID_COLOR) tex = ld3(M.color); // solid_color.rs:24-28
                             else tex = texture_value_deferred(A, BVH ? A.textures : lds_textures, M.texture, h.u, h.v, h.point, noise_tex);
+                            // emission (the path ends) or attenuation, one copy for all three; a Noise colour arrives below
+                            if (!TEXTURED || noise_tex < 0) T = T * tex;
                         }
                         RT_REGION(9); // texture, step 1
-                        // emission (the path ends) or attenuation, one copy for all three; a Noise colour arrives below
-                        if (kind != RT_MAT_DIELECTRIC && (!TEXTURED || noise_tex < 0)) T = T * tex;
                         if (kind == RT_MAT_DIFFUSE_LIGHT) { // diffuse_light.rs:25-37
                             ended = true;
                             if (TEXTURED) o = h.point; // a Noise light is finished below
-                        } else if (kind == RT_MAT_LAMBERTIAN) { // lambertian.rs:26-38 (direction below)
+                        } else if (!SPECULAR || kind == RT_MAT_LAMBERTIAN) { // lambertian.rs:26-38 (direction below)
                             o = h.point;
                             d = h.normal; // the incoming direction is dead: lambertian.rs:27 starts from the normal
                             is_lambert = true;
@@ -711,7 +713,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                             cand_base = 0;
                             waiting = fuzz != 0.0; // fuzz 0 multiplies the sample by 0: its draws are dead
                             finish = !waiting;
-                        } else if (SPECULAR) { // dialectric.rs:25-55
+                        } else { // dialectric.rs:25-55
                             const double ratio = h.front ? M.color[0] : M.ior; // 1 / ior, divided at upload
                             const d3 ud = unit_fast(d);
                             const double cos_theta = fmin(dot(-ud, h.normal), 1.0);
@@ -733,9 +735,6 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                             }
                             o = h.point;
                             scattered = true;
-                        } else { // unreachable: the host picks SPECULAR whenever such a material exists
-                            T = mk(0.0, 0.0, 0.0);
-                            ended = true;
                         }
                     }
                 }
