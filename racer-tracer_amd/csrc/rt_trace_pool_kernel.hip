@@ -696,26 +696,37 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                             if (!TEXTURED || noise_tex < 0) T = T * tex;
                         }
                         RT_REGION(9); // texture, step 1
+                        // With four arms, what every material does with the hit goes before the switch: a value
+                        // assigned in one arm only costs every arm a copy where they meet (C2 -1.7 %; with the two
+                        // arms of the other variants the same hoist costs C3 1 %).  A light ends the path, the point
+                        // of a Noise light is read below; hit_normal and fuzz are Metal's, dead for the others.
+                        const d3 d_in = d;
+                        if (SPECULAR) {
+                            o = h.point;
+                            cand_base = 0;
+                            hit_normal = h.normal;
+                            fuzz = M.fuzz;
+                        }
                         if (kind == RT_MAT_DIFFUSE_LIGHT) { // diffuse_light.rs:25-37
                             ended = true;
-                            if (TEXTURED) o = h.point; // a Noise light is finished below
+                            if (!SPECULAR && TEXTURED) o = h.point;
                         } else if (!SPECULAR || kind == RT_MAT_LAMBERTIAN) { // lambertian.rs:26-38 (direction below)
-                            o = h.point;
+                            if (!SPECULAR) {
+                                o = h.point;
+                                cand_base = 0;
+                            }
                             d = h.normal; // the incoming direction is dead: lambertian.rs:27 starts from the normal
                             is_lambert = true;
                             waiting = true;
-                            cand_base = 0;
-                        } else if (SPECULAR && kind == RT_MAT_METAL) { // metal.rs:26-43 (fuzz below)
-                            o = h.point;
-                            hit_normal = h.normal;
-                            fuzz = M.fuzz;
+                        } else if (SPECULAR && kind == RT_MAT_METAL) { // metal.rs:26-43
+                            const d3 ud = unit_fast(d_in);
+                            d = ud - (2.0 * dot(ud, h.normal)) * h.normal; // metal.rs:30 reflect(); the fuzz term follows below
                             is_lambert = false;
-                            cand_base = 0;
                             waiting = fuzz != 0.0; // fuzz 0 multiplies the sample by 0: its draws are dead
                             finish = !waiting;
                         } else { // dialectric.rs:25-55
                             const double ratio = h.front ? M.color[0] : M.ior; // 1 / ior, divided at upload
-                            const d3 ud = unit_fast(d);
+                            const d3 ud = unit_fast(d_in);
                             const double cos_theta = fmin(dot(-ud, h.normal), 1.0);
                             const double sin_theta = sqrt_fast(1.0 - cos_theta * cos_theta);
                             bool reflect_it = ratio * sin_theta > 1.0;
@@ -733,7 +744,6 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                                 const d3 perp = ratio * (ud + cos_theta * h.normal);
                                 d = perp + (-sqrt_fast(fabs(1.0 - len2(perp)))) * h.normal;
                             }
-                            o = h.point;
                             scattered = true;
                         }
                     }
@@ -771,17 +781,22 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
             if (finish) {
                 if (is_lambert) { // lambertian.rs:27-33
                     const d3 dir = d + unit_fast(sph); // d holds the normal since the hit
-                    if (!(fabs(dir.x) < 1e-8 && fabs(dir.y) < 1e-8 && fabs(dir.z) < 1e-8)) d = dir;
+                    // vec3.rs:127-130 near_zero keeps the normal: once in 10^23 samples, so the wave branches
+                    // around the six selects it would otherwise issue every time
+                    const bool near_zero = fabs(dir.x) < 1e-8 && fabs(dir.y) < 1e-8 && fabs(dir.z) < 1e-8;
+                    const d3 normal = d;
+                    d = dir;
+                    if (__ballot(near_zero) != 0) {
+                        asm volatile("; near_zero (keeps the compiler from turning the branch back into selects)");
+                        if (near_zero) d = normal;
+                    }
                     scattered = true;
-                } else if (SPECULAR) { // metal.rs:30-42
-                    const d3 ud = unit_fast(d);
-                    d3 dir = ud - (2.0 * dot(ud, hit_normal)) * hit_normal;
-                    if (fuzz != 0.0) dir = dir + fuzz * sph;
-                    if (dot(dir, hit_normal) < 0.0) {
+                } else if (SPECULAR) { // metal.rs:31-42: d holds the reflected direction since the hit
+                    if (fuzz != 0.0) d = d + fuzz * sph;
+                    if (dot(d, hit_normal) < 0.0) {
                         T = mk(0.0, 0.0, 0.0);
                         ended = true;
                     } else {
-                        d = dir;
                         scattered = true;
                     }
                 }
