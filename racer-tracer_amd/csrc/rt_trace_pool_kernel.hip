@@ -50,6 +50,11 @@
 // 7. THE ONE EXPENSIVE TEXTURE IS EVALUATED BY THE WHOLE WAVE (coop_noise_turbulence): lanes only note
 //    their Noise lookup while shading; eight lookups per round take eight lanes each, one octave per lane.
 //
+// 8. A PATH CARRIES ORIGIN, DIRECTION, THROUGHPUT AND NOTHING ELSE WHILE IT WAITS.  A hit's point overwrites the ray
+//    origin, its attenuation is multiplied into the throughput at once, a Lambertian hit's normal overwrites the ray
+//    direction (the incoming one is dead), and a finished path's contribution is formed in the throughput.  Every
+//    value kept beside those cost registers and, where the material arms meet, a copy per arm.
+//
 // The launch is VALU-throughput bound (DESIGN.md 4.2 has the counters, the per-region
 // cycle profile of the -DRT_PROFILE_REGIONS build, and the variants that were measured and
 // dropped).
