@@ -248,6 +248,9 @@ void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtd
         a.bvh_center[k] = s->bvh_center[k];
     }
     a.bvh_lds_nodes = s->bvh_nodes_in_lds ? s->n_bvh_nodes : 0;
+    a.leaf_geo = s->leaf_geo.ptr;
+    a.leaf_time_a = s->leaf_time_a;
+    a.leaf_inv_dt = s->leaf_inv_dt;
     for (int g = 0; g < 3; ++g) a.rect_end[g] = s->rect_end[g];
     a.sphere_end = s->sphere_end;
 #ifdef RT_DEVELOPER_KNOBS // throw-away kernel knobs of the developer build (tools/perf_ab.sh)
@@ -460,6 +463,7 @@ void rt_scene_destroy(RtScene *s) {
     s->perlins.release();
     s->bvh_nodes.release();
     s->bvh_prim_index.release();
+    s->leaf_geo.release();
     s->accum.release();
     s->partial.release();
     s->queue.release();
@@ -626,7 +630,26 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
         prims.swap(sorted);
     }
     if (s->use_bvh) {
-        rtdev::BvhBuild bvh = rtdev::build_bvh(d->primitives, d->n_primitives);
+        // Primitives per leaf.  A leaf primitive costs a lane four times what a node costs (its record comes from
+        // global memory, the node from LDS; `random`: 40 % of the walk for 5.8 tests against 26.5 nodes per
+        // segment), so leaves of three beat leaves of four (66.1 -> 62.1 ms) — as long as the larger node array
+        // does not cost the variant a block per CU (leaves of two: 70.6 ms with three blocks instead of four).
+        const size_t lds_other = s->textured && d->n_perlins > 0 && s->perlin_identity ? sizeof(double) * 256 * 3 : 0;
+        auto blocks_with = [&](const rtdev::BvhBuild &b) {
+            const size_t bytes = b.nodes.size() * sizeof(rtdev::BvhNode);
+            return rtdev_pool_blocks_per_cu(s->prims_class, s->textured, s->specular, 1, (bytes <= 32 * 1024 ? bytes : 0) + lds_other);
+        };
+        rtdev::BvhBuild bvh = rtdev::build_bvh(d->primitives, d->n_primitives, 4);
+        int max_leaf = 0;
+#ifdef RT_DEVELOPER_KNOBS
+        if (const char *k = getenv("RT_BVH_LEAF")) max_leaf = atoi(k);
+#endif
+        if (max_leaf > 0) {
+            bvh = rtdev::build_bvh(d->primitives, d->n_primitives, max_leaf);
+        } else if (bvh.nodes.size() * sizeof(rtdev::BvhNode) <= 32 * 1024) { // the nodes live in LDS
+            rtdev::BvhBuild three = rtdev::build_bvh(d->primitives, d->n_primitives, 3);
+            if (three.nodes.size() * sizeof(rtdev::BvhNode) <= 32 * 1024 && blocks_with(three) == blocks_with(bvh)) bvh = std::move(three);
+        }
         if ((rc = upload(s->bvh_nodes, bvh.nodes)) != RT_OK) return rc;
         if ((rc = upload(s->bvh_prim_index, bvh.prim_index)) != RT_OK) return rc;
         s->n_bvh_nodes = (int)bvh.nodes.size();
@@ -639,6 +662,29 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
         std::vector<rtdev::Prim> ordered(prims.size());
         for (size_t j = 0; j < bvh.prim_index.size(); ++j) ordered[j] = prims[(size_t)bvh.prim_index[j]];
         prims.swap(ordered);
+        // the compact records the walk tests leaves with; the first MovingSphere sets the scene-wide time interval
+        std::vector<rtdev::LeafGeo> geo(prims.size());
+        bool have_interval = false;
+        for (size_t j = 0; j < prims.size(); ++j) {
+            const rtdev::Prim &q = prims[j];
+            rtdev::LeafGeo &g = geo[j];
+            memset(&g, 0, sizeof g);
+            g.tag = 1;
+            if (q.flags != 0 || (q.kind != RT_PRIM_SPHERE && q.kind != RT_PRIM_MOVING_SPHERE)) continue;
+            if (q.kind == RT_PRIM_MOVING_SPHERE) {
+                if (!have_interval) {
+                    s->leaf_time_a = q.rot_sin;
+                    s->leaf_inv_dt = q.rot_cos;
+                    have_interval = true;
+                }
+                if (q.rot_sin != s->leaf_time_a || q.rot_cos != s->leaf_inv_dt) continue; // another interval: general path
+                for (int k = 0; k < 3; ++k) g.dc[k] = q.tr[k];
+            }
+            for (int k = 0; k < 3; ++k) g.c0[k] = q.p[k];
+            g.radius2 = q.radius2;
+            g.tag = 0;
+        }
+        if ((rc = upload(s->leaf_geo, geo)) != RT_OK) return rc;
     }
     if ((rc = upload(s->prims, prims)) != RT_OK) return rc;
     if ((rc = upload(s->textures, textures)) != RT_OK) return rc;
@@ -942,10 +988,11 @@ int rt_scene_last_stats(RtScene *s, RtRenderStats *out) {
         const unsigned long long *c = counters;
         static const char *names[16] = {"item setup", "batches", "hand-out + primary ray", "closest hit", "miss / material",
                                         "sampler", "scatter + accumulate", "item end", "hit record", "texture, step 1",
-                                        "Noise rounds", "-", "-", "-", "-", "-"};
+                                        "Noise rounds", "BVH: descent to a leaf", "BVH: leaf primitives", "-", "-", "-"};
         double total = 0;
         for (int k = 0; k < 16; ++k) total += (double)c[rtdev::RT_STAT_REGIONS + k];
-        for (int k = 0; k < 11; ++k)
+        for (int k = 0; k < 13; ++k)
+            if (k < 11 || c[rtdev::RT_STAT_REGIONS + k])
             fprintf(stderr, "region %-24s %6.2f %%  (%.3g wave-cycles, %4.1f lanes active at its closing marker)\n", names[k],
                     100.0 * (double)c[rtdev::RT_STAT_REGIONS + k] / total, (double)c[rtdev::RT_STAT_REGIONS + k],
                     c[rtdev::RT_STAT_REGIONS + k] ? (double)c[rtdev::RT_STAT_REGION_LANES + k] / (double)c[rtdev::RT_STAT_REGIONS + k] : 0.0);

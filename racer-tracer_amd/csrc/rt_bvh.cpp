@@ -72,7 +72,7 @@ struct Item {
 };
 
 // Emits the subtree over items[begin, end) in depth-first order; returns its root index.
-int emit(Build64 &out, std::vector<Item> &items, int begin, int end) {
+int emit(Build64 &out, std::vector<Item> &items, int begin, int end, int max_leaf) {
     int me = (int)out.nodes.size();
     out.nodes.emplace_back();
     double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
@@ -85,14 +85,14 @@ int emit(Build64 &out, std::vector<Item> &items, int begin, int end) {
             cmx[k] = std::max(cmx[k], items[(size_t)i].centroid[k]);
         }
     int n = end - begin;
-    bool leaf = n <= 4;
+    bool leaf = n <= max_leaf;
     int axis = 0;
     if (!leaf) {
         for (int k = 1; k < 3; ++k)
             if (cmx[k] - cmn[k] > cmx[axis] - cmn[axis]) axis = k;
         if (!(cmx[axis] - cmn[axis] > 0.0)) leaf = n <= 64; // coincident centroids: splitting cannot separate them
     }
-    if (leaf && n > 4) { // degenerate pile: chain of 4-primitive leaves under one box
+    if (leaf && n > max_leaf) { // degenerate pile: chain of full leaves under one box
         leaf = false;
         axis = -1;
     }
@@ -153,13 +153,13 @@ int emit(Build64 &out, std::vector<Item> &items, int begin, int end) {
         });
         mid = best_mid;
     } else {
-        mid = begin + 4;
+        mid = begin + max_leaf;
     }
     node.first = -1;
     node.count = 0;
     out.nodes[(size_t)me] = node;
-    emit(out, items, begin, mid);
-    emit(out, items, mid, end);
+    emit(out, items, begin, mid, max_leaf);
+    emit(out, items, mid, end, max_leaf);
     out.nodes[(size_t)me].skip = (int32_t)out.nodes.size();
     return me;
 }
@@ -176,7 +176,9 @@ float round_up(double x) {
 
 } // namespace
 
-BvhBuild build_bvh(const RtPrimitive *prims, int n_prims) {
+BvhBuild build_bvh(const RtPrimitive *prims, int n_prims, int max_leaf) {
+    if (max_leaf < 1) max_leaf = 1;
+    if (max_leaf > 7) max_leaf = 7; // BvhNode.first_count keeps the count in three bits
     BvhBuild out;
     for (int k = 0; k < 3; ++k) out.root_mn[k] = out.root_mx[k] = out.center[k] = 0.0;
     if (n_prims <= 0) return out;
@@ -189,7 +191,7 @@ BvhBuild build_bvh(const RtPrimitive *prims, int n_prims) {
     }
     Build64 tree;
     tree.nodes.reserve((size_t)n_prims);
-    emit(tree, items, 0, n_prims);
+    emit(tree, items, 0, n_prims, max_leaf);
     out.prim_index = tree.prim_index;
     // Device form: f32 boxes around the root's centre.  A ray is clipped to the root box in f64 before the walk, so
     // its origin is at most `extent` from the centre and the f32 slab test is off by a few 2^-24 * extent in the

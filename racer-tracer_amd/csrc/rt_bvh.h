@@ -32,7 +32,7 @@ struct BvhBuild {
 };
 
 // Host-side build over the ABI primitives (wrappers and motion included in the bounds).
-BvhBuild build_bvh(const RtPrimitive *prims, int n_prims);
+BvhBuild build_bvh(const RtPrimitive *prims, int n_prims, int max_leaf = 4); // max_leaf: primitives per leaf, 1..7
 // True bounds of one primitive incl. RotateY / Translate / motion.
 void primitive_bounds(const RtPrimitive &p, double mn[3], double mx[3]);
 

@@ -81,6 +81,18 @@ struct alignas(16) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 32, "BvhNode must be 32 bytes");
 
+// What the BVH walk needs to TEST a leaf primitive, 64 B instead of the 128 B of a Prim record it would touch: a
+// lane's leaf tests are gathers from global memory (the table is in leaf order; `random`: 40 % of the walk), and
+// a gather costs the L1 one pass per lane and instruction.  tag 0: an unwrapped Sphere or MovingSphere whose
+// centre is c0 + ((time - leaf_time_a) * leaf_inv_dt) * dc (moving_sphere.rs:37-39; dc = 0 for a Sphere), with
+// the scene-wide time interval of TraceArgs; tag 1: anything else — the walk then reads the Prim record.
+struct alignas(64) LeafGeo {
+    double c0[3], radius2;
+    double dc[3];
+    int64_t tag;
+};
+static_assert(sizeof(LeafGeo) == 64, "LeafGeo must be 64 bytes");
+
 struct Camera { // what get_ray reads (camera.rs:326-337)
     double origin[3], ulc[3], right[3], up[3], horizontal[3], vertical[3];
     double lens_radius;
@@ -160,6 +172,8 @@ struct TraceArgs {
     const int32_t *bvh_prim_index;
     int32_t n_bvh_nodes;
     int32_t bvh_lds_nodes; // == n_bvh_nodes when the node array is staged in dynamic LDS, else 0
+    const LeafGeo *leaf_geo;             // per primitive of the (leaf-ordered) table
+    double leaf_time_a, leaf_inv_dt;     // MovingSphere.time_a and 1 / (time_b - time_a) of the tag-0 records
     // Linear-loop variants: the device table is grouped — untransformed XY rects first, then XZ, then YZ
     // (rect_end[a] is the end of group a), then untransformed spheres (sphere_end), then everything else
     // (boxes, moving spheres, wrapped primitives) — so that the closest-hit loop runs one straight-line test

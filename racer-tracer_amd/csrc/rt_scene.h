@@ -69,6 +69,8 @@ struct RtScene {
     int use_bvh = 0;
     rtapi::DevBuf<rtdev::BvhNode> bvh_nodes;
     rtapi::DevBuf<int32_t> bvh_prim_index;
+    rtapi::DevBuf<rtdev::LeafGeo> leaf_geo; // what a leaf test reads (rt_device_types.h)
+    double leaf_time_a = 0.0, leaf_inv_dt = 1.0;
     int n_bvh_nodes = 0;
     double bvh_root_mn[3] = {0, 0, 0}, bvh_root_mx[3] = {0, 0, 0}, bvh_center[3] = {0, 0, 0};
     bool bvh_nodes_in_lds = false; // node array (32 B each) staged in dynamic LDS when <= 32 KiB

@@ -263,6 +263,25 @@ __device__ __forceinline__ void box_side(const double *p, int s, int &axis, doub
     else { a0 = p[1]; a1 = p[4]; b0 = p[2]; b1 = p[5]; k = (s & 1) ? p[0] : p[3]; }
 }
 
+// sphere.rs:39-59: nearest root of the half-b quadratic in [t_min, t_max]
+__device__ __forceinline__ bool sphere_t(d3 center, double radius2, d3 o, d3 d, double inv_a, double t_min, double t_max,
+                                         double &t_out) {
+    const d3 oc = o - center;
+    const double a = len2(d);
+    const double half_b = dot(oc, d);
+    const double c = len2(oc) - radius2;
+    const double disc = half_b * half_b - a * c;
+    if (disc < 0.0) return false;
+    const double sqrtd = sqrt_fast(disc);
+    double root = div_by(-half_b - sqrtd, a, inv_a); // sphere.rs:52 divides by a
+    if (root < t_min || t_max < root) {
+        root = div_by(-half_b + sqrtd, a, inv_a);
+        if (root < t_min || t_max < root) return false;
+    }
+    t_out = root;
+    return true;
+}
+
 // Nearest t of primitive P in [t_min, t_max], wrappers applied
 // (translate.rs:31, rotate_y.rs:39-48).  aux = box side.
 template <int PRIMS>
@@ -291,20 +310,7 @@ __device__ __forceinline__ bool prim_t(const Prim &P, d3 o, d3 d, d3 inv_d, doub
         d3 center = ld3(P.p);
         if (PRIMS == PRIMS_ANY && P.kind == RT_PRIM_MOVING_SPHERE)
             center = center + ((time - P.rot_sin) * P.rot_cos) * ld3(P.tr); // tr = pos_b - pos_a, rot_* = time_a, 1/(time_b - time_a)
-        d3 oc = o - center;
-        double a = len2(d);
-        double half_b = dot(oc, d);
-        double c = len2(oc) - P.radius2;
-        double disc = half_b * half_b - a * c;
-        if (disc < 0.0) return false;
-        double sqrtd = sqrt_fast(disc);
-        double root = div_by(-half_b - sqrtd, a, inv_a); // sphere.rs:52 divides by a
-        if (root < t_min || t_max < root) {
-            root = div_by(-half_b + sqrtd, a, inv_a);
-            if (root < t_min || t_max < root) return false;
-        }
-        t_out = root;
-        return true;
+        return sphere_t(center, P.radius2, o, d, inv_a, t_min, t_max, t_out);
     }
     case RT_PRIM_XY_RECT: return rect_t<true>(2, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, t_min, t_max, t_out);
     case RT_PRIM_XZ_RECT: return rect_t<true>(1, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, t_min, t_max, t_out);
@@ -337,10 +343,13 @@ __device__ __forceinline__ bool prim_t(const Prim &P, d3 o, d3 d, d3 inv_d, doub
 // leaf whose box it hits (or has left the tree), THEN the wave tests leaf
 // primitives together.  Mixing the two in one loop body makes a wave pay the
 // primitive tests on almost every step (measured 1.35 -> see DESIGN.md).
-template <int PRIMS>
+struct NoMark { // profile hook of closest_hit_bvh: the regions build passes one that books cycles
+    __device__ __forceinline__ void operator()(int) const {}
+};
+template <int PRIMS, class Mark = NoMark>
 __device__ __forceinline__ void closest_hit_bvh(const TraceArgs &A, const BvhNode *nodes, d3 o, d3 d, d3 inv_d,
                                                 double inv_a, double time, double t_min, double &best_t, int &best,
-                                                int &best_aux, unsigned *walk_stats = nullptr) {
+                                                int &best_aux, unsigned *walk_stats = nullptr, Mark mark = Mark()) {
     // CULLING IN SINGLE PRECISION.  The node boxes only decide which primitives get tested (in f64, as everywhere),
     // so they are f32 boxes around the root's centre, 32 B per node.  The ray is first clipped to the root box in
     // f64: from there its origin is within the scene's extent E of the centre, the f32 plane distances below are
@@ -392,13 +401,22 @@ __device__ __forceinline__ void closest_hit_bvh(const TraceArgs &A, const BvhNod
                 i = N->skip;
             }
         }
+        mark(11); // profile build: the descent
         bool improved = false;
         for (int k = 0; k < count; ++k) { // the leaf's primitives (stored contiguously in leaf order)
             if (walk_stats) ++walk_stats[1]; // profile build: primitives tested
             const int pi = first + k;
             double t;
-            int aux;
-            if (prim_t<PRIMS>(A.prims[pi], o, d, inv_d, inv_a, time, t_min, best_t, t, aux)) {
+            int aux = 0;
+            bool hit;
+            const LeafGeo &G = A.leaf_geo[pi];
+            if (G.tag == 0) { // sphere.rs:39-59 / moving_sphere.rs:49-69 from the compact record
+                const d3 center = ld3(G.c0) + ((time - A.leaf_time_a) * A.leaf_inv_dt) * ld3(G.dc);
+                hit = sphere_t(center, G.radius2, o, d, inv_a, t_min, best_t, t);
+            } else {
+                hit = prim_t<PRIMS>(A.prims[pi], o, d, inv_d, inv_a, time, t_min, best_t, t, aux);
+            }
+            if (hit) {
                 best_t = t;
                 best = pi;
                 best_aux = aux;
@@ -406,6 +424,7 @@ __device__ __forceinline__ void closest_hit_bvh(const TraceArgs &A, const BvhNod
             }
         }
         if (improved) best_f = far_of(best_t);
+        mark(12); // profile build: the leaf
     }
 }
 

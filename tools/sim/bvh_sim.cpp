@@ -1,0 +1,230 @@
+// bvh_sim.cpp — CPU model of two closest-hit walks over the `random` scene's BVH: how many boxes and primitives does
+// a ray touch, and how many steps does a WAVE of 64 rays take (it pays for its slowest lane)?
+//   (a) the skip-link walk of rt_trace_common.h: closest_hit_bvh (one box per step, fixed child order)
+//   (b) an ordered walk with a stack over the same tree: both children's boxes per step, nearer child first
+// Rays: primary rays of the scene camera in scanline order, then one bounce in a cosine-ish random direction.
+//   g++ -O2 -std=c++17 -Iinclude -Iracer-tracer_amd -o racer-tracer_amd/build/bvh_sim tools/sim/bvh_sim.cpp \
+//       racer-tracer_amd/build/product/rt_bvh.o -Lracer-tracer_amd/lib -lracer_tracer_amd -Wl,-rpath,$PWD/racer-tracer_amd/lib
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+#include "rt_abi.h"
+#include "rt_host.h"
+#include "csrc/rt_bvh.h"
+
+struct Ray { double o[3], d[3], time; };
+struct Tree { // binary tree recovered from the skip-link array
+    std::vector<int> left, right; // inner: child node indices; leaf: -1
+};
+
+static bool hit_box(const rtdev::BvhNode &n, const double c[3], const Ray &r, double tmax, double &tnear) {
+    double t0 = 0.001, t1 = tmax;
+    for (int k = 0; k < 3; ++k) {
+        const double inv = 1.0 / r.d[k];
+        double a = ((double)n.mn[k] + c[k] - r.o[k]) * inv, b = ((double)n.mx[k] + c[k] - r.o[k]) * inv;
+        if (a > b) std::swap(a, b);
+        t0 = std::max(t0, a);
+        t1 = std::min(t1, b);
+    }
+    tnear = t0;
+    return t0 <= t1;
+}
+static bool hit_prim(const RtPrimitive &p, const Ray &r, double tmax, double &t) {
+    double c[3];
+    for (int k = 0; k < 3; ++k) c[k] = p.p[k];
+    if (p.kind == RT_PRIM_MOVING_SPHERE) {
+        const double f = (r.time - p.time_a) / (p.time_b - p.time_a);
+        for (int k = 0; k < 3; ++k) c[k] += f * (p.center_b[k] - p.p[k]);
+    }
+    double oc[3] = {r.o[0] - c[0], r.o[1] - c[1], r.o[2] - c[2]};
+    const double a = r.d[0] * r.d[0] + r.d[1] * r.d[1] + r.d[2] * r.d[2];
+    const double hb = oc[0] * r.d[0] + oc[1] * r.d[1] + oc[2] * r.d[2];
+    const double cc = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2] - p.p[3] * p.p[3];
+    const double disc = hb * hb - a * cc;
+    if (disc < 0) return false;
+    const double sq = std::sqrt(disc);
+    double root = (-hb - sq) / a;
+    if (root < 0.001 || root > tmax) {
+        root = (-hb + sq) / a;
+        if (root < 0.001 || root > tmax) return false;
+    }
+    t = root;
+    return true;
+}
+
+struct Count { long boxes = 0, prims = 0, steps = 0; };
+
+int main(int argc, char **argv) {
+    RthSession *session = nullptr;
+    if (rth_session_open("scenes/config_c2.yml", "random", nullptr, 1, &session) != RT_OK) {
+        fprintf(stderr, "%s\n", rth_last_error_message());
+        return 1;
+    }
+    const RtSceneDesc *d = rth_session_scene(session);
+    const RtCamera *cam = rth_session_camera(session);
+    const int max_leaf = argc > 1 ? atoi(argv[1]) : 4;
+    rtdev::BvhBuild bvh = rtdev::build_bvh(d->primitives, d->n_primitives, max_leaf);
+    printf("max %d primitives per leaf: ", max_leaf);
+    const int n = (int)bvh.nodes.size();
+    Tree tree;
+    tree.left.assign(n, -1);
+    tree.right.assign(n, -1);
+    int leaves = 0, max_depth = 0;
+    { // children of inner node i: i + 1 and skip(i + 1)
+        std::vector<std::pair<int, int>> st = {{0, 1}};
+        while (!st.empty()) {
+            auto [i, depth] = st.back();
+            st.pop_back();
+            max_depth = std::max(max_depth, depth);
+            if (bvh.nodes[i].first_count & 7) { ++leaves; continue; }
+            tree.left[i] = i + 1;
+            tree.right[i] = bvh.nodes[i + 1].skip;
+            st.push_back({tree.left[i], depth + 1});
+            st.push_back({tree.right[i], depth + 1});
+        }
+    }
+    printf("%d primitives, %d nodes (%d leaves, %d inner), depth %d\n", d->n_primitives, n, leaves, n - leaves, max_depth);
+
+    const int W = 480, H = 270;
+    std::mt19937_64 rng(7);
+    std::uniform_real_distribution<double> U(0.0, 1.0);
+    std::vector<Ray> rays;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            Ray r;
+            const double u = (x + U(rng)) / (W - 1), v = (y + U(rng)) / (H - 1);
+            for (int k = 0; k < 3; ++k) {
+                r.o[k] = cam->origin[k];
+                r.d[k] = cam->upper_left_corner[k] + u * cam->horizontal[k] - v * cam->vertical[k] - cam->origin[k];
+            }
+            r.time = U(rng);
+            rays.push_back(r);
+        }
+    auto closest_linear = [&](const Ray &r, int &best) {
+        double bt = INFINITY;
+        best = -1;
+        for (int i = 0; i < d->n_primitives; ++i) {
+            double t;
+            if (hit_prim(d->primitives[i], r, bt, t)) { bt = t; best = i; }
+        }
+        return bt;
+    };
+    auto walk_skip = [&](const Ray &r, Count &c, int &best) {
+        double bt = INFINITY;
+        best = -1;
+        int i = 0, steps = 0;
+        while (i < n) {
+            ++c.boxes; ++steps;
+            double tn;
+            if (hit_box(bvh.nodes[i], bvh.center, r, bt, tn)) {
+                const int fc = bvh.nodes[i].first_count;
+                for (int k = 0; k < (fc & 7); ++k) {
+                    ++c.prims;
+                    const int pi = bvh.prim_index[(fc >> 3) + k];
+                    double t;
+                    if (hit_prim(d->primitives[pi], r, bt, t)) { bt = t; best = pi; }
+                }
+                i = i + 1;
+            } else {
+                i = bvh.nodes[i].skip;
+            }
+        }
+        return steps;
+    };
+    auto walk_ordered = [&](const Ray &r, Count &c, int &best, int &max_sp) {
+        double bt = INFINITY;
+        best = -1;
+        int stack[64], sp = 0, cur = 0, steps = 0;
+        auto leaf = [&](int i) {
+            const int fc = bvh.nodes[i].first_count;
+            for (int k = 0; k < (fc & 7); ++k) {
+                ++c.prims;
+                const int pi = bvh.prim_index[(fc >> 3) + k];
+                double t;
+                if (hit_prim(d->primitives[pi], r, bt, t)) { bt = t; best = pi; }
+            }
+        };
+        double tn;
+        ++c.boxes;
+        if (!hit_box(bvh.nodes[0], bvh.center, r, bt, tn)) return 1;
+        for (;;) {
+            ++steps;
+            if (tree.left[cur] < 0) {
+                leaf(cur);
+                if (sp == 0) break;
+                cur = stack[--sp];
+                continue;
+            }
+            const int L = tree.left[cur], R = tree.right[cur];
+            double tl, tr;
+            c.boxes += 2;
+            const bool hl = hit_box(bvh.nodes[L], bvh.center, r, bt, tl), hr = hit_box(bvh.nodes[R], bvh.center, r, bt, tr);
+            if (hl && hr) {
+                const bool lfirst = tl <= tr;
+                stack[sp++] = lfirst ? R : L;
+                max_sp = std::max(max_sp, sp);
+                cur = lfirst ? L : R;
+            } else if (hl || hr) {
+                cur = hl ? L : R;
+            } else {
+                if (sp == 0) break;
+                cur = stack[--sp];
+            }
+        }
+        return steps;
+    };
+    // NOTE the ordered walk re-tests a popped node's box implicitly never: a popped far child may have become
+    // prunable (best_t shrank); count that variant too
+    for (int bounce = 0; bounce < 3; ++bounce) {
+        Count a, b;
+        long wave_a = 0, wave_b = 0, mismatches = 0;
+        int max_sp = 0;
+        std::vector<Ray> next;
+        for (size_t w = 0; w < rays.size(); w += 64) {
+            int ma = 0, mb = 0;
+            for (size_t j = w; j < std::min(rays.size(), w + 64); ++j) {
+                int ba, bb;
+                ma = std::max(ma, walk_skip(rays[j], a, ba));
+                mb = std::max(mb, walk_ordered(rays[j], b, bb, max_sp));
+                mismatches += ba != bb;
+                if (ba >= 0) { // bounce: origin at the hit, direction normal + random unit vector
+                    int bl;
+                    const double t = closest_linear(rays[j], bl);
+                    mismatches += bl != ba;
+                    const RtPrimitive &p = d->primitives[ba];
+                    Ray r;
+                    double c[3], nrm[3], len = 0;
+                    for (int k = 0; k < 3; ++k) c[k] = p.p[k];
+                    if (p.kind == RT_PRIM_MOVING_SPHERE) {
+                        const double f = (rays[j].time - p.time_a) / (p.time_b - p.time_a);
+                        for (int k = 0; k < 3; ++k) c[k] += f * (p.center_b[k] - p.p[k]);
+                    }
+                    for (int k = 0; k < 3; ++k) {
+                        r.o[k] = rays[j].o[k] + t * rays[j].d[k];
+                        nrm[k] = (r.o[k] - c[k]) / p.p[3];
+                    }
+                    double v[3];
+                    do {
+                        len = 0;
+                        for (int k = 0; k < 3; ++k) { v[k] = 2 * U(rng) - 1; len += v[k] * v[k]; }
+                    } while (len >= 1 || len == 0);
+                    for (int k = 0; k < 3; ++k) r.d[k] = nrm[k] + v[k] / std::sqrt(len);
+                    r.time = rays[j].time;
+                    next.push_back(r);
+                }
+            }
+            wave_a += ma;
+            wave_b += mb;
+        }
+        const double nr = (double)rays.size(), nw = std::ceil(nr / 64);
+        printf("bounce %d: %zu rays | skip-link: %.1f boxes %.1f prims per ray, %.1f steps per wave | ordered+stack: %.1f boxes %.1f prims per ray, "
+               "%.1f steps per wave (2 boxes each), stack depth %d | closest hits differ: %ld\n",
+               bounce, rays.size(), a.boxes / nr, a.prims / nr, wave_a / nw, b.boxes / nr, b.prims / nr, wave_b / nw, max_sp, mismatches);
+        rays.swap(next);
+    }
+    rth_session_close(session);
+    return 0;
+}
