@@ -134,6 +134,39 @@ int main(int argc, char **argv) {
         }
         return steps;
     };
+    // (c) skip links, two nodes per step: node i and its layout successor i + 1 are fetched and tested together; when
+    //     the walk goes on at i + 1 anyway (i is a hit inner node, or a missed node whose skip link is i + 1) the
+    //     second result is used at once.  No stack, no new layout.
+    auto walk_two = [&](const Ray &r, Count &c, int &best) {
+        double bt = INFINITY;
+        best = -1;
+        int i = 0, steps = 0;
+        auto leaf = [&](int j) {
+            const int fc = bvh.nodes[j].first_count;
+            for (int k = 0; k < (fc & 7); ++k) {
+                ++c.prims;
+                const int pi = bvh.prim_index[(fc >> 3) + k];
+                double t;
+                if (hit_prim(d->primitives[pi], r, bt, t)) { bt = t; best = pi; }
+            }
+        };
+        while (i < n) {
+            ++steps;
+            double tn;
+            c.boxes += i + 1 < n ? 2 : 1;
+            const bool ha = hit_box(bvh.nodes[i], bvh.center, r, bt, tn);
+            const bool hb = i + 1 < n && hit_box(bvh.nodes[i + 1], bvh.center, r, bt, tn);
+            const bool a_leaf = (bvh.nodes[i].first_count & 7) != 0;
+            if (ha && a_leaf) { leaf(i); i = i + 1; continue; }
+            const bool next_is_b = ha || bvh.nodes[i].skip == i + 1;
+            if (!next_is_b) { i = bvh.nodes[i].skip; continue; }
+            if (i + 1 >= n) break;
+            if (!hb) { i = bvh.nodes[i + 1].skip; continue; }
+            if (bvh.nodes[i + 1].first_count & 7) { leaf(i + 1); i = i + 2; continue; }
+            i = i + 2;
+        }
+        return steps;
+    };
     auto walk_ordered = [&](const Ray &r, Count &c, int &best, int &max_sp) {
         double bt = INFINITY;
         best = -1;
@@ -179,17 +212,18 @@ int main(int argc, char **argv) {
     // NOTE the ordered walk re-tests a popped node's box implicitly never: a popped far child may have become
     // prunable (best_t shrank); count that variant too
     for (int bounce = 0; bounce < 3; ++bounce) {
-        Count a, b;
-        long wave_a = 0, wave_b = 0, mismatches = 0;
+        Count a, b, c2;
+        long wave_a = 0, wave_b = 0, wave_c = 0, mismatches = 0;
         int max_sp = 0;
         std::vector<Ray> next;
         for (size_t w = 0; w < rays.size(); w += 64) {
-            int ma = 0, mb = 0;
+            int ma = 0, mb = 0, mc = 0;
             for (size_t j = w; j < std::min(rays.size(), w + 64); ++j) {
                 int ba, bb;
                 ma = std::max(ma, walk_skip(rays[j], a, ba));
                 mb = std::max(mb, walk_ordered(rays[j], b, bb, max_sp));
                 mismatches += ba != bb;
+                { int bc; mc = std::max(mc, walk_two(rays[j], c2, bc)); mismatches += bc != ba; }
                 if (ba >= 0) { // bounce: origin at the hit, direction normal + random unit vector
                     int bl;
                     const double t = closest_linear(rays[j], bl);
@@ -218,11 +252,12 @@ int main(int argc, char **argv) {
             }
             wave_a += ma;
             wave_b += mb;
+            wave_c += mc;
         }
         const double nr = (double)rays.size(), nw = std::ceil(nr / 64);
         printf("bounce %d: %zu rays | skip-link: %.1f boxes %.1f prims per ray, %.1f steps per wave | ordered+stack: %.1f boxes %.1f prims per ray, "
-               "%.1f steps per wave (2 boxes each), stack depth %d | closest hits differ: %ld\n",
-               bounce, rays.size(), a.boxes / nr, a.prims / nr, wave_a / nw, b.boxes / nr, b.prims / nr, wave_b / nw, max_sp, mismatches);
+               "%.1f steps per wave (2 boxes each), stack depth %d | skip-link, two per step: %.1f boxes, %.1f steps per wave | closest hits differ: %ld\n",
+               bounce, rays.size(), a.boxes / nr, a.prims / nr, wave_a / nw, b.boxes / nr, b.prims / nr, wave_b / nw, max_sp, c2.boxes / nr, wave_c / nw, mismatches);
         rays.swap(next);
     }
     rth_session_close(session);
