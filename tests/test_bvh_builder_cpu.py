@@ -1,0 +1,38 @@
+"""The device BVH builder (racer-tracer_amd/csrc/rt_bvh.cpp) is host code: tools/sim/bvh_sim.cpp walks the tree it
+builds for the `random` scene on the CPU — by skip links (the device walk), by skip links two nodes at a time and in
+near-to-far order with a stack — over a frame of primary rays and two bounces, and compares every closest hit with a
+linear scan over the primitives."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "racer-tracer_amd")
+
+
+@pytest.fixture(scope="module")
+def bvh_sim():
+    obj = os.path.join(PKG, "build", "product", "rt_bvh.o")
+    lib = os.path.join(PKG, "lib", "libracer_tracer_amd.so")
+    if not (os.path.exists(obj) and os.path.exists(lib)):
+        pytest.skip("the library has not been built (python -c 'import __graft_entry__ as g; g.build()')")
+    exe = os.path.join(PKG, "build", "bvh_sim")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + PKG, "-o", exe,
+                    os.path.join(ROOT, "tools", "sim", "bvh_sim.cpp"), obj, "-L" + os.path.join(PKG, "lib"),
+                    "-lracer_tracer_amd", "-Wl,-rpath," + os.path.join(PKG, "lib")], check=True, cwd=ROOT)
+    return exe
+
+
+@pytest.mark.parametrize("max_leaf", [1, 3, 4, 7])
+def test_every_walk_finds_the_linear_scan_hit(bvh_sim, max_leaf):
+    out = subprocess.run([bvh_sim, str(max_leaf)], check=True, cwd=ROOT, capture_output=True, text=True).stdout
+    head = re.search(r"(\d+) primitives, (\d+) nodes \((\d+) leaves, (\d+) inner\), depth (\d+)", out)
+    n_prims, n_nodes, leaves, inner, depth = map(int, head.groups())
+    assert n_prims == 485 and leaves == inner + 1 and n_nodes == leaves + inner      # a full binary tree
+    assert leaves >= (n_prims + max_leaf - 1) // max_leaf and depth <= 24
+    bounces = re.findall(r"bounce (\d): (\d+) rays .* closest hits differ: (\d+)", out)
+    assert [b[0] for b in bounces] == ["0", "1", "2"]
+    for _, rays, differ in bounces:
+        assert int(rays) > 10000 and int(differ) == 0

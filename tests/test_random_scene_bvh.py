@@ -214,3 +214,40 @@ def test_gpu_small_scene_forced_through_bvh(rt, orc, gpu):
         a, _ = render_gpu(rt, bundle, camera, params, abi.RT_HIT_LINEAR)
         b, _ = render_gpu(rt, bundle, camera, params, abi.RT_HIT_BVH)
         assert same_frame(a, b), fn.__name__
+
+
+def moving_mix_scene(n=90, seed=11):
+    """Static spheres, MovingSpheres on TWO different time intervals and a ground rect: the BVH walk tests leaves
+    from its compact records (unwrapped spheres on the scene-wide interval — that of the first MovingSphere) or
+    from the Prim records (the other interval, the rect)."""
+    rng = np.random.default_rng(seed)
+    textures = [abi.solid(tuple(rng.random(3) * 0.8 + 0.1)) for _ in range(5)]
+    materials = [abi.material(S.L, i) for i in range(4)] + [abi.material(S.M, 4, fuzz=0.2)]
+    prims = [abi.rect(abi.RT_PRIM_XZ_RECT, -30, 30, -30, 30, 0.0, 0, 1)]
+    for i in range(n):
+        c = rng.random(3) * np.array([24.0, 3.0, 24.0]) - np.array([12.0, -0.4, 12.0])
+        m = int(rng.integers(0, len(materials)))
+        r = float(rng.random() * 0.5 + 0.2)
+        if i % 3 == 0:
+            prims.append(abi.sphere(tuple(c), r, m, i + 2))
+        else:
+            interval = (0.0, 1.0) if i % 3 == 1 else (-0.5, 1.5)   # both contain the camera's shutter [0, 1]
+            prims.append(abi.moving_sphere(tuple(c), tuple(c + rng.random(3) - 0.5), r, m, i + 2, *interval))
+    bundle = abi.SceneBundle(prims, materials, textures, abi.sky())
+    cam = dict(look_from=(0, 4, 18), look_at=(0, 1, 0), vfov=35.0, aperture=0.0, focus_distance=10.0)
+    return bundle, cam
+
+
+@pytest.mark.gpu
+def test_gpu_bvh_leaf_records_with_two_time_intervals(rt, orc, gpu):
+    bundle, cam = moving_mix_scene()
+    w, h, spp = 96, 54, 8
+    camera = S.camera_for(cam, w, h)
+    params = abi.render_params(w, h, spp)
+    ref, ref_segs = orc.render(bundle.desc, camera, params, use_bvh=0)
+    bvh, st = render_gpu(rt, bundle, camera, params)
+    lin, _ = render_gpu(rt, bundle, camera, params, abi.RT_HIT_LINEAR)
+    assert same_frame(bvh, lin)
+    d = np.abs(bvh - ref)
+    assert d.max() < 1e-3 and float((d.max(axis=-1) > 1e-9).mean()) < 2e-3
+    assert abs(int(st.segments) - ref_segs) <= 4
