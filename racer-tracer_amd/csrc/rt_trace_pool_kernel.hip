@@ -189,9 +189,10 @@ __device__ __forceinline__ bool coop_random_in_unit_sphere(bool need, uint32_t p
             if (need) {
                 const u4 b0 = philox4x32(pixel, sample, (seg << 8) | RT_RNG_SCATTER, 2u * base, k0, k1);
                 const u4 b1 = philox4x32(pixel, sample, (seg << 8) | RT_RNG_SCATTER, 2u * base + 1u, k0, k1);
-                const d3 p = mk(sym53(b0.a, b0.b), sym53(b0.c, b0.d), sym53(b1.a, b1.b));
-                if (len2(p) < 1.0) {
-                    result = p;
+                // `result` only means something to a lane that returns true: a lane that still needs a sample
+                // may take every candidate it looks at, rejected ones included, without a select
+                result = mk(sym53(b0.a, b0.b), sym53(b0.c, b0.d), sym53(b1.a, b1.b));
+                if (len2(result) < 1.0) {
                     need = false;
                     have = true;
                 } else {
@@ -219,8 +220,8 @@ __device__ __forceinline__ bool coop_random_in_unit_sphere(bool need, uint32_t p
         const bool got = mine != 0;
         const int src = got ? first + __ffsll((unsigned long long)mine) - 1 : lane;
         const double rx = __shfl(p.x, src, 64), ry = __shfl(p.y, src, 64), rz = __shfl(p.z, src, 64);
+        if (need) result = mk(rx, ry, rz); // (its own candidate's coordinates when it got none: see above)
         if (got) {
-            result = mk(rx, ry, rz);
             need = false;
             have = true;
         } else if (need) {
