@@ -185,10 +185,32 @@ def test_cancel_during_render_returns_ok_and_stops_the_tile_stream(rt, orc, gpu)
         # what was delivered is a prefix of the column-major tile list (cpu.rs:91-113)
         expect = [(108 * hs, 192 * ws) for ws in range(10) for hs in range(10)]
         assert [(t[0], t[1]) for t in tiles] == expect[:len(tiles)]
-        # the scene is still usable afterwards
+        # the scene is still usable afterwards (the poisoned item counters are reset by the next call)
         flag.value = 0
         small = S.abi.render_params(64, 36, 4, tiles_w=2, tiles_h=2)
-        assert len(scene.render_tiles(S.camera_for(cam, 64, 36), small, cancel=C.pointer(flag))) == 4
+        small_cam = S.camera_for(cam, 64, 36)
+        after = scene.render_tiles(small_cam, small, cancel=C.pointer(flag))
+        assert len(after) == 4
+        fresh = rt.Scene(bundle)
+        try:
+            whole = fresh.render_frame(small_cam, small)
+        finally:
+            fresh.close()
+        for r, c, tw, th, arr in after:
+            assert np.array_equal(arr, whole[r:r + th, c:c + tw])
+        assert np.array_equal(scene.render_frame(small_cam, small), whole)
+        # the whole-frame path (a single tile column is cut from the finished frame) stops the same way
+        flag.value = 0
+        timer = threading.Timer(0.05, raise_flag)
+        del raised[:]
+        timer.start()
+        one_column = S.abi.render_params(w, h, spp, tiles_w=1, tiles_h=4)
+        tiles = scene.render_tiles(camera, one_column, cancel=C.pointer(flag))
+        returned = time.time()
+        timer.join()
+        assert tiles == [] and returned - raised[0] < 0.06        # cpu.rs:55-62: Ok(()), no tile written
+        flag.value = 0
+        assert np.array_equal(scene.render_frame(small_cam, small), whole)
     finally:
         scene.close()
 
