@@ -56,6 +56,15 @@ __global__ void k(const double *x, double *out, int n) {
     }
 }
 
+__global__ void k_fixup(const double *x, double *out, int n) { // rt_trace_common.h: rcp_f64
+    const int i = threadIdx.x;
+    if (i >= n) return;
+    const double v = x[i];
+    const double r0 = __builtin_amdgcn_rcp(v);
+    const double e = fma(-v, r0, 1.0);
+    out[i] = __builtin_amdgcn_div_fixup(fma(r0, fma(e, e, e), r0), v, 1.0);
+}
+
 static double ulps(double got, long double want) {
     int ex;
     frexpl(want, &ex);
@@ -83,6 +92,15 @@ int main() {
     const char *names[N_SCHEMES] = {"v_rcp_f64 seed", "rcp: two Newton steps (4 fma)", "rcp: one cubic step (3 fma)",
                                     "v_rsq_f64 seed", "rsqrt: Goldschmidt x2 (8 ops)", "rsqrt: one cubic step (5 ops)",
                                     "sqrt: Goldschmidt + correction (7 ops)", "sqrt: cubic step (5 ops)", "sqrt: cubic step + correction (8 ops)"};
+    { // the special arguments rcp_f64's v_div_fixup_f64 is there for: 1/x of +-0, +-inf, NaN, a denormal
+        const double special[8] = {0.0, -0.0, INFINITY, -INFINITY, NAN, 4.9406564584124654e-324, 1e-310, 1.7976931348623157e308};
+        CHECK(hipMemcpy(dx, special, sizeof special, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_fixup, dim3(1), dim3(64), 0, 0, dx, dout, 8);
+        CHECK(hipDeviceSynchronize());
+        double got[8];
+        CHECK(hipMemcpy(got, dout, sizeof got, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 8; ++i) printf("rcp with v_div_fixup_f64: 1 / %-24.17g = %-24.17g (IEEE division: %.17g)\n", special[i], got[i], 1.0 / special[i]);
+    }
     for (int s = 0; s < N_SCHEMES; ++s) {
         double worst = 0, sum = 0;
         long exact = 0;
