@@ -146,7 +146,9 @@ def pmc_summary(workload, workload_name, world):
 def valu_roofline(c, kernel_ms, segments):
     """VALU-issue view of one launch.  SQ_ACTIVE_INST_VALU counts, per SIMD, cycles/4 with a vector
     instruction executing (MI355X_MICROARCH.md, SQ counters): x4 = busy SIMD-cycles.  Peak = every SIMD
-    busy every cycle of the LIVE kernel duration at the peak clock."""
+    busy every cycle of the LIVE kernel duration at the peak clock.  (Four cycles are booked per instruction,
+    but plain 32-bit VOP2 instructions issue in 2.3 — tools/microbench/valu_cost.hip — so two waves' bookings
+    can overlap and the fraction can pass 1 by a few per cent at six waves per SIMD: it means "at the limit".)"""
     busy_cycles = 4.0 * c["SQ_ACTIVE_INST_VALU"]["mean"]
     secs = kernel_ms * 1e-3
     achieved = busy_cycles / secs / 1e9
@@ -159,6 +161,9 @@ def valu_roofline(c, kernel_ms, segments):
             "lanes_per_inst": round(lanes, 1),
             "useful_lane_frac": round(achieved / peak * lanes / 64.0, 4),
             "kernel_ms_under_pmc": c["_stamp"].get("kernel_ms_under_pmc"),
+            "note": "the counter books 4 cycles per vector instruction; plain 32-bit VOP2 instructions issue in 2.3 "
+                    "(profiles/r02_valu_cost.txt), so with several waves per SIMD the sum can pass the SIMD-cycles "
+                    "available: a frac near or above 1 says the launch is at the VALU issue limit",
             "source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU (own pass), %s, "
                       "source stamp %s" % (c["_path"], c["_stamp"]["source_sha"][:12])}
 

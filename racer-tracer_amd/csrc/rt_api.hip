@@ -234,6 +234,7 @@ void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtd
         a.cam.vertical[k] = c->vertical[k];
     }
     a.cam.lens_radius = c->lens_radius;
+    a.lens_lds = c->lens_radius != 0.0;
     a.cam.time_a = c->time_a;
     a.cam.time_b = c->time_b;
     a.bg = s->bg;
@@ -344,7 +345,7 @@ int rtapi::enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderPara
             if ((uint64_t)a.n_chunks * (uint64_t)a.n_tiles >= 0x40000000ull) // the item counter's top bit is the cancel poison
                 return fail(RT_ERR_UNSUPPORTED, "more than 2^30 work items in one launch");
             a.queue = s->queue.ptr + (size_t)win.index * (size_t)n_batches + launches;
-            unsigned blocks = (unsigned)(s->num_cus * s->pool_blocks_per_cu);
+            unsigned blocks = (unsigned)(s->num_cus * (a.lens_lds ? s->pool_blocks_per_cu_lens : s->pool_blocks_per_cu));
             unsigned needed = (a.n_items + 3) / 4;
             if (blocks > needed) blocks = needed;
             RT_HIP(rtdev_launch_trace_pool(&a, s->prims_class, s->textured, s->specular, s->use_bvh, blocks, stream));
@@ -386,19 +387,13 @@ int wait_event(hipEvent_t ev, const volatile int *cancel) {
 
 // Ends the pool launches of the current call early: every item counter of the call becomes 2^31
 // (enqueue_render keeps a launch below 2^30 items, so no count of further hand-outs wraps it).
-// The copy runs on its own stream, beside the kernels it stops.
+// The counters are written by the command processor (hipStreamWriteValue32 on a third stream): that needs
+// neither a compute unit nor a copy engine.  A 4-byte hipMemcpyAsync was measured first — the runtime runs it
+// as a kernel, which found no room beside six resident blocks per CU until the column in flight had finished
+// (50 ms instead of one item's 10).
 int poison_queue(RtScene *s) {
-    const size_t slots = s->queue.count;
-    if (slots == 0) return RT_OK;
-    if (s->poison_count < slots) {
-        if (s->poison) (void)hipHostFree(s->poison);
-        s->poison = nullptr;
-        s->poison_count = 0;
-        RT_HIP(hipHostMalloc((void **)&s->poison, slots * sizeof(unsigned int), hipHostMallocDefault));
-        s->poison_count = slots;
-        for (size_t i = 0; i < slots; ++i) s->poison[i] = 0x80000000u;
-    }
-    RT_HIP(hipMemcpyAsync(s->queue.ptr, s->poison, slots * sizeof(unsigned int), hipMemcpyHostToDevice, s->stream_ctl));
+    for (size_t i = 0; i < s->queue.count; ++i)
+        RT_HIP(hipStreamWriteValue32(s->stream_ctl, s->queue.ptr + i, 0x80000000u, 0));
     RT_HIP(hipStreamSynchronize(s->stream_ctl));
     return RT_OK;
 }
@@ -480,7 +475,6 @@ void rt_scene_destroy(RtScene *s) {
     if (s->stream) (void)hipStreamDestroy(s->stream);
     if (s->stream2) (void)hipStreamDestroy(s->stream2);
     if (s->stream_ctl) (void)hipStreamDestroy(s->stream_ctl);
-    if (s->poison) (void)hipHostFree(s->poison);
     delete s;
 }
 
@@ -711,9 +705,11 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
                                        : (size_t)s->n_prims * sizeof(rtdev::Prim) + (s->textured ? (size_t)s->n_textures * sizeof(rtdev::Texture) : 0)) +
                            (s->textured && s->n_perlins > 0 && s->perlin_identity ? sizeof(double) * 256 * 3 : 0);
     s->pool_blocks_per_cu = rtdev_pool_blocks_per_cu(s->prims_class, s->textured, s->specular, s->use_bvh, dyn_lds);
+    s->pool_blocks_per_cu_lens = rtdev_pool_blocks_per_cu(s->prims_class, s->textured, s->specular, s->use_bvh,
+                                                          dyn_lds + rtdev::pool_lens_lds_bytes(s->use_bvh != 0));
 #ifdef RT_DEVELOPER_KNOBS // occupancy experiments
     if (const char *k = getenv("RT_POOL_BLOCKS_PER_CU"))
-        if (atoi(k) > 0) s->pool_blocks_per_cu = atoi(k);
+        if (atoi(k) > 0) s->pool_blocks_per_cu = s->pool_blocks_per_cu_lens = atoi(k);
 #endif
     RT_HIP(s->segments.alloc(rtdev::RT_STAT_SLOTS)); // rt_device_types.h: RT_STAT_*
     RT_HIP(hipMemset(s->segments.ptr, 0, rtdev::RT_STAT_SLOTS * sizeof(unsigned long long)));

@@ -93,6 +93,10 @@ struct alignas(64) LeafGeo {
 };
 static_assert(sizeof(LeafGeo) == 64, "LeafGeo must be 64 bytes");
 
+// dynamic LDS of the pooled kernel's lens-disk samples per block: 4 waves x NBUF batches x 64 entries x (x, y);
+// NBUF = 1 in the BVH variants, 2 elsewhere (rt_trace_pool_kernel.hip: WaveLds)
+inline size_t pool_lens_lds_bytes(bool bvh) { return (size_t)4 * (bvh ? 1 : 2) * 64 * 2 * sizeof(double); }
+
 struct Camera { // what get_ray reads (camera.rs:326-337)
     double origin[3], ulc[3], right[3], up[3], horizontal[3], vertical[3];
     double lens_radius;
@@ -180,6 +184,7 @@ struct TraceArgs {
     // per group instead of a scalar switch on the kind of every record.
     int32_t rect_end[3];
     int32_t sphere_end;
+    int32_t lens_lds;      // the camera has an aperture: the lens-disk samples of the batches sit at the end of dynamic LDS
     int32_t dbg[4];        // developer knobs (env RT_DBG0..3), 0 in production
 };
 

@@ -78,6 +78,7 @@ struct RtScene {
     // pooled kernel (default): persistent grid = CUs x resident blocks of the variant
     bool use_v1 = false;   // RtSceneOptions.kernel == RT_KERNEL_V1: the lane-per-pixel kernel
     int num_cus = 0, pool_blocks_per_cu = 1;
+    int pool_blocks_per_cu_lens = 1; // ... when the camera has an aperture (its lens samples take dynamic LDS)
     rtapi::DevBuf<double> partial;       // [chunks][H][W][3] per-chunk sums
     rtapi::DevBuf<unsigned int> queue;   // one item counter per launch of a render call
     int last_chunks = 0;
@@ -94,10 +95,7 @@ struct RtScene {
     double *pinned[2] = {nullptr, nullptr};
     size_t pinned_count[2] = {0, 0};
     hipEvent_t ev_column[2] = {nullptr, nullptr};
-    // rt_render's cancel: a pinned array of poisoned item counters and the stream that copies it over the
-    // launches' counters (rt_api.hip: poison_queue)
-    unsigned int *poison = nullptr;
-    size_t poison_count = 0;
+    // rt_render's cancel: the stream whose command processor overwrites the launches' item counters (rt_api.hip: poison_queue)
     hipStream_t stream_ctl = nullptr;
     hipStream_t last_stream = nullptr;
     bool has_stats = false;

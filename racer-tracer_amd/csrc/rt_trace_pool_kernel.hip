@@ -154,6 +154,9 @@ union SamplerScratch {
 
 // Per-wave scratch in LDS.  HAS_TIME: the scene has MovingSpheres (PRIMS_ANY variants).
 // NBUF: batches of camera samples kept (2, or 1 for the BVH variants, whose node array wants the LDS).
+// The lens-disk samples of a batch (16 B per entry) are NOT in here: only a camera with an aperture draws them, and
+// without their 8 KB per block the plain variants fit six blocks per CU instead of five (cornell 85.2 -> 82.1 ms).
+// They live behind everything else in DYNAMIC LDS, which the launch sizes by the camera (TraceArgs.lens_lds).
 template <bool HAS_TIME, int NBUF> struct WaveLds {
     // per pixel of the item's tile: upper_left_corner + u * horizontal with the pixel's ONE
     // horizontal jitter u = (px + ju) / (W - 1) (cpu.rs:35-36, camera.rs:331)
@@ -164,7 +167,6 @@ template <bool HAS_TIME, int NBUF> struct WaveLds {
     // Camera samples of the pool entries, drawn 64 entries at a time by the WHOLE wave
     // (prepare_batch below): entry w sits in slot w & 63 of buffer (w >> 6) & (NBUF - 1).
     double v[NBUF][64];        // (py + jv) / (H - 1)                      cpu.rs:39-40
-    double lens[NBUF][64][2];  // random_in_unit_disk of the entry        camera.rs:327
     double time[HAS_TIME ? NBUF : 1][HAS_TIME ? 64 : 1]; // ray time      camera.rs:335
 };
 
@@ -368,6 +370,14 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
         }
         __syncthreads();
     }
+    // the lens-disk samples of this wave's batches: [NBUF][64][2] doubles per wave behind the tables above (see WaveLds)
+    double (*lens)[64][2] = nullptr;
+    if (A.lens_lds) {
+        size_t at = BVH ? (size_t)A.bvh_lds_nodes * sizeof(BvhNode)
+                        : (size_t)A.n_prims * sizeof(Prim) + (TEXTURED ? (size_t)A.n_textures * sizeof(Texture) : 0);
+        if (TEXTURED && A.perlin_in_lds) at += sizeof(PerlinGradients);
+        lens = reinterpret_cast<double (*)[64][2]>(dyn_lds + at) + (threadIdx.x >> 6) * NBUF;
+    }
     // BVH nodes are staged in dynamic LDS when they fit (the host sets bvh_lds_nodes):
     // a traversal step is a dependent load, and ~100 steps at
     // L2 latency with 3-4 waves per SIMD is what bounds the big-scene variants.
@@ -503,8 +513,8 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
             if (K->cam.lens_radius != 0.0) {
                 double lx = 0.0, ly = 0.0;
                 coop_random_in_unit_disk(in_pool, pixel_b, sample_b, A.seed_lo, A.seed_hi, lane, L.scratch.req, lx, ly);
-                L.lens[buf][lane][0] = lx;
-                L.lens[buf][lane][1] = ly;
+                lens[buf][lane][0] = lx;
+                lens[buf][lane][1] = ly;
             }
         };
 
@@ -562,7 +572,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                     d = ld3(L.base[pix]) - v * ld3(K->cam.vertical) - co;
                     const double lr = K->cam.lens_radius;
                     if (lr != 0.0) {
-                        const d3 offset = ld3(K->cam.right) * (L.lens[buf][slot][0] * lr) + ld3(K->cam.up) * (L.lens[buf][slot][1] * lr);
+                        const d3 offset = ld3(K->cam.right) * (lens[buf][slot][0] * lr) + ld3(K->cam.up) * (lens[buf][slot][1] * lr);
                         o = co + offset;
                         d = d - offset;
                     }
@@ -889,7 +899,8 @@ template <int PRIMS, bool TEXTURED, bool SPECULAR, bool BVH> struct PoolVariant 
     static void launch(const rtdev::TraceArgs &a, unsigned blocks, hipStream_t stream) {
         const size_t dyn = (BVH ? (size_t)a.bvh_lds_nodes * sizeof(rtdev::BvhNode)
                                 : (size_t)a.n_prims * sizeof(rtdev::Prim) + (TEXTURED ? (size_t)a.n_textures * sizeof(rtdev::Texture) : 0)) +
-                           (TEXTURED && a.perlin_in_lds ? sizeof(double) * 256 * 3 : 0);
+                           (TEXTURED && a.perlin_in_lds ? sizeof(double) * 256 * 3 : 0) +
+                           (a.lens_lds ? rtdev::pool_lens_lds_bytes(BVH) : 0);
         hipLaunchKernelGGL((rtdev::k_trace_pool_f64<PRIMS, TEXTURED, SPECULAR, BVH>), dim3(blocks), dim3(256), dyn, stream, a);
     }
     static int blocks_per_cu(size_t dyn_lds) {
