@@ -74,6 +74,12 @@
 #ifndef RT_OCC_SPEC
 #define RT_OCC_SPEC 5
 #endif
+#ifndef RT_OCC_ANY
+#define RT_OCC_ANY 4 // untextured linear-loop variants with any primitive kind
+#endif
+#ifndef RT_OCC_PLAIN
+#define RT_OCC_PLAIN 5 // rects-only / spheres-only, no textures, no specular materials: 79 VGPRs, so six blocks per CU fit when LDS allows
+#endif
 namespace rtdev {
 
 // -DRT_PROFILE_REGIONS: developer build that accumulates the shader-clock cycles each wave
@@ -341,7 +347,7 @@ __device__ __forceinline__ double coop_noise_turbulence(bool need, d3 p, int dep
 // BVH: closest hit through the skip-link hierarchy instead of the linear loop
 // (instantiated for PRIMS_ANY only; chosen for scenes with many primitives).
 template <int PRIMS, bool TEXTURED, bool SPECULAR, bool BVH>
-__global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC_TEX_BVH : RT_OCC_TEX_ANY) : RT_OCC_TEX) : ((BVH || PRIMS == PRIMS_ANY) ? 4 : (SPECULAR ? RT_OCC_SPEC : 5))) void k_trace_pool_f64(const TraceArgs A) {
+__global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC_TEX_BVH : RT_OCC_TEX_ANY) : RT_OCC_TEX) : (BVH ? 4 : (PRIMS == PRIMS_ANY ? RT_OCC_ANY : (SPECULAR ? RT_OCC_SPEC : RT_OCC_PLAIN)))) void k_trace_pool_f64(const TraceArgs A) {
     // Two batches of camera samples stay ahead of the hand-out, so that it may straddle a batch
     // boundary; the BVH variants keep one (their node array wants the LDS: three resident blocks
     // instead of two on the `random` scene) and a hand-out stops at the end of its batch.
