@@ -52,8 +52,8 @@ BYTES_PER_SEGMENT_F64 = 192.0  # 96-B f64 ray record read + writ
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
