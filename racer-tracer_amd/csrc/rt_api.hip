@@ -392,8 +392,13 @@ int wait_event(hipEvent_t ev, const volatile int *cancel) {
 // as a kernel, which found no room beside six resident blocks per CU until the column in flight had finished
 // (50 ms instead of one item's 10).
 int poison_queue(RtScene *s) {
-    for (size_t i = 0; i < s->queue.count; ++i)
-        RT_HIP(hipStreamWriteValue32(s->stream_ctl, s->queue.ptr + i, 0x80000000u, 0));
+    bool by_cp = true;
+    for (size_t i = 0; i < s->queue.count && by_cp; ++i)
+        by_cp = hipStreamWriteValue32(s->stream_ctl, s->queue.ptr + i, 0x80000000u, 0) == hipSuccess;
+    if (!by_cp) { // a runtime without stream memory operations: a fill kernel does it, once it finds room
+        (void)hipGetLastError();
+        RT_HIP(hipMemsetD32Async((hipDeviceptr_t)s->queue.ptr, (int)0x80000000u, s->queue.count, s->stream_ctl));
+    }
     RT_HIP(hipStreamSynchronize(s->stream_ctl));
     return RT_OK;
 }
