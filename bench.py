@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group and run the strip gather as a collective even with "
+                         "ONE rank (proves librccl + an f64 device gather on a one-GPU box)")
     return ap.parse_args()
 
 
@@ -188,6 +191,9 @@ def spawn_ranks(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
            os.path.abspath(__file__)] + sys.argv[1:]
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver only supports dmabuf IPC; with the legacy mode RCCL's
+    # (and torch's) cross-process sharing of device memory fails with `hipIpcGetMemHandle: invalid argument`.
+    # The image exports it already; it is repeated here so the ranks have it under any launcher environment.
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
     line = None
@@ -208,7 +214,7 @@ def spawn_ranks(args):
 
 def main():
     args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))  # before torch / HIP are even imported
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -228,7 +234,7 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         if rehearsal:
             dist.init_process_group("gloo")
@@ -244,9 +250,9 @@ def main():
 
     scene = rt.Scene(session, device=local)
     strips = importlib.import_module("racer-tracer_amd.strips")
-    gatherer = strips.StripGather(H, W, STRIP_ROWS, world, rank, "cuda", dist)
-    # for N > 1 the frame lives in the gather's staging buffer: no copies besides the strips
-    frame = gatherer.frame() if world > 1 else torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
+    gatherer = strips.StripGather(H, W, STRIP_ROWS, world, rank, "cuda", dist, always_collective=args.force_dist)
+    # when a collective runs the frame lives in the gather's staging buffer: no copies besides the strips
+    frame = gatherer.frame() if gatherer.collective else torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream()
     kernel_ms, segments = [], []
 
@@ -312,7 +318,9 @@ def main():
             "data": "synthetic (the reference's own scene YAML; counter-based RNG, seed %d)" % p.seed,
             "config": {"workload": workload, "strip_rows": STRIP_ROWS,
                        "parallelism": "image rows interleaved over %d GPU(s)%s"
-                                      % (world, ", RCCL gather to rank 0" if world > 1 else "")},
+                                      % (world, "" if dist is None else
+                                         (", gloo gather to rank 0 (one-card rehearsal, NOT RCCL)" if rehearsal
+                                          else ", RCCL gather to rank 0"))},
             "roofline": {
                 "bound": "valu",
                 "achieved": None, "peak": round(SIMDS * CLOCK_GHZ, 1), "unit": "G busy SIMD-cycles/s", "frac": None,
@@ -346,6 +354,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(session, args.cpu_seconds)
         if rehearsal:
             out["rehearsal"] = "N ranks on ONE GPU over gloo: functional check only"
+        if args.force_dist:
+            out["force_dist"] = "backend %s, world %d: process group initialised, strips gathered with dist.gather" % (
+                dist.get_backend(), world)
+        if rehearsal or args.force_dist:
             # the gathered frame must equal a single-rank render of the same frame
             p.strip_count = 0
             whole = torch.zeros_like(frame)

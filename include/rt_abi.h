@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 3
+#define RT_ABI_VERSION 4
 
 /* ------------------------------------------------------------------ errors
  * 0 = Ok.  1..22 are exactly the reference's exit codes
@@ -312,7 +312,11 @@ void rt_scene_destroy(RtScene *scene);
 /* Replaces `CpuRenderer::render` (renderer/cpu.rs:118-131) with the whole
  * frame as ONE BufferUpdate (legal: renderer/image.rs:56-62 does the same).
  * out_rgb: caller-owned HOST memory, width*height*3 f64, row-major, row 0 =
- * top; gamma-encoded (sqrt(sum/samples)), not tone-mapped, not clamped. */
+ * top; gamma-encoded (sqrt(sum/samples)), not tone-mapped, not clamped.
+ * The launch writes finished pixels into pinned memory itself, band of rows by
+ * band of rows, and the call copies a finished band into out_rgb while the GPU
+ * renders the next: the frame is in out_rgb a fraction of a millisecond after
+ * the last wave ends (no resolve launch, no device-to-host copy afterwards). */
 int rt_render_frame(RtScene *scene, const RtCamera *camera, const RtRenderParams *params,
                     double *out_rgb);
 
@@ -324,23 +328,38 @@ int rt_render_frame_device(RtScene *scene, const RtCamera *camera,
                            const RtRenderParams *params, double *out_rgb_device,
                            void *hip_stream);
 
+/* Cancel hook of rt_render_ex / rt_render_multi = `do_cancel` (renderer.rs:25-30):
+ * returns non-zero once the render should stop.  The reference's
+ * `RenderData.cancel_event` is an `Option<&synchronoise::SignalEvent>` polled with
+ * `wait_timeout(Duration::ZERO)`; a binding passes a function that does exactly
+ * that.  Called on the calling thread only, between
+ * launches, before every tile callback and every few tens of microseconds while
+ * the call waits for the GPU. */
+typedef int (*RtCancelCallback)(void *cancel_user);
+
 /* Replaces `CpuRenderer::render` with the reference's own tile stream:
  * tiles_w x tiles_h tiles in column-major order with the last row/column
  * absorbing remainders (cpu.rs:73-115), one callback per tile, on the
- * calling thread.  Delivery is progressive: a tile column is traced, resolved
- * and copied while the callbacks of the previous column run, so tiles arrive
- * during the render as the reference's do (cpu.rs:64-70); their pixels are
- * bit-identical to rt_render_frame's.  `cancel` (may be NULL) is polled like
- * `do_cancel` (renderer.rs:25-30) before every launch and every callback and
+ * calling thread.  Delivery is progressive: ONE launch renders the frame tile
+ * column by tile column and writes finished pixels straight into pinned host
+ * memory; the callbacks of a finished column run while the GPU works on the
+ * next, so tiles arrive during the render as the reference's do (cpu.rs:64-70);
+ * their pixels are bit-identical to rt_render_frame's.  `cancel` (may be NULL)
+ * is polled like `do_cancel` (renderer.rs:25-30) before every callback and
  * while the call waits for the GPU: once it is non-zero the waves in flight
  * stop at their next work item, the call returns RT_OK and emits nothing
  * further; tiles delivered before stay delivered (cpu.rs:55-62).  Passing a
  * flag costs nothing while it stays zero.  If it is already set on entry the
  * call returns RT_ERR_CANCEL_EVENT (cpu.rs:82-85).
  * params->strip_count > 1 is refused (RT_ERR_INVALID_ARGUMENT): tiles are finished pieces of the
- * frame.  rt_scene_last_stats after this call: kernel_ms spans all columns. */
+ * frame.  rt_scene_last_stats after this call: kernel_ms spans the launch. */
 int rt_render(RtScene *scene, const RtCamera *camera, const RtRenderParams *params,
               RtTileCallback callback, void *user, const volatile int *cancel);
+
+/* rt_render with the cancel hook as a FUNCTION (NULL = never cancelled): the form a
+ * binding of the reference uses, whose cancel event is an object, not an int in memory. */
+int rt_render_ex(RtScene *scene, const RtCamera *camera, const RtRenderParams *params,
+                 RtTileCallback callback, void *user, RtCancelCallback cancelled, void *cancel_user);
 
 /* What the reference does to a finished tile downstream of the renderer, on
  * the device: ScreenBuffer::update's tone map (image_buffer.rs:147-153) and
@@ -368,14 +387,19 @@ int rt_render_frame_rgba8(RtScene *scene, const RtCamera *camera, const RtRender
  * that should take part (a device may appear twice: two scenes on it share it).
  * The frame is cut into strips of `strip_rows` rows (0 = 8), strip j belongs to
  * scenes[j % n_scenes]; every device traces its strips concurrently on its own
- * stream and the finished strips are collected
- *   - rt_render_frame_multi:        straight into out_rgb (HOST memory), each
- *     device copying its own strips over its own PCIe link;
- *   - rt_render_frame_multi_device: into out_rgb_device, memory of
- *     scenes[0]'s device, by peer copies over xGMI (one strided
- *     hipMemcpy2DAsync per device on that device's stream; a single process
- *     needs no RCCL rendezvous for that — the multi-PROCESS path gathers with
- *     RCCL, racer-tracer_amd/strips.py).  Synchronises before returning.
+ * stream and the finished pixels are collected
+ *   - rt_render_frame_multi:        in out_rgb (HOST memory): every device writes
+ *     its finished pixels over its own PCIe link into one pinned frame, which the
+ *     call copies to out_rgb band by band while the devices render on;
+ *   - rt_render_frame_multi_device: in out_rgb_device, memory of scenes[0]'s
+ *     device, by peer copies over xGMI (one hipMemcpyPeerAsync per strip on the
+ *     SOURCE device's stream behind its resolve pass; a single process needs no
+ *     RCCL rendezvous for that — the multi-PROCESS path gathers with RCCL,
+ *     racer-tracer_amd/strips.py).  Synchronises before returning;
+ *   - rt_render_multi:              as rt_render_ex's tile stream: a tile column
+ *     is handed to the callback as soon as EVERY device has finished its strips
+ *     of it (same order, same tiles, same cancel behaviour as rt_render_ex), so
+ *     a several-GPU `impl Renderer` keeps progressive delivery and cancel.
  * params->strip_* must be unset (the call sets them per device) and
  * params->scale <= 1.  The frame is bit-identical to rt_render_frame's for
  * every n_scenes when strip_rows is a multiple of 8 (the RNG is addressed by the
@@ -386,6 +410,8 @@ int rt_render_frame_multi(RtScene *const *scenes, int n_scenes, const RtCamera *
                           const RtRenderParams *params, int strip_rows, double *out_rgb);
 int rt_render_frame_multi_device(RtScene *const *scenes, int n_scenes, const RtCamera *camera,
                                  const RtRenderParams *params, int strip_rows, double *out_rgb_device);
+int rt_render_multi(RtScene *const *scenes, int n_scenes, const RtCamera *camera, const RtRenderParams *params,
+                    int strip_rows, RtTileCallback callback, void *user, RtCancelCallback cancelled, void *cancel_user);
 
 /* Stats of the most recent render call on this scene (synchronises the
  * stream of that call first). */

@@ -94,6 +94,25 @@ def render_frame_multi_device(scenes, camera, params, out_ptr, strip_rows=0):
                                              C.c_void_p(out_ptr)), "rt_render_frame_multi_device")
 
 
+def _tile_collector(tiles):
+    def on_tile(_user, rgb, r, c, w, h):
+        arr = np.ctypeslib.as_array(rgb, shape=(h, w, 3)).copy()  # `rgb` is only valid during the callback
+        tiles.append((r, c, w, h, arr))
+    return on_tile
+
+
+def render_tiles_multi(scenes, camera, params, strip_rows=0, cancel=None):
+    """rt_render_multi: the tile stream of one frame rendered by several Scene objects (one per device share)
+    -> list of (r, c, width, height, float64 [height, width, 3]); cancel: None or a callable."""
+    tiles = []
+    cb = abi.RtTileCallback(_tile_collector(tiles))
+    hook = abi.RtCancelCallback(lambda _user: 1 if cancel() else 0) if cancel is not None else C.cast(None, abi.RtCancelCallback)
+    handles = (C.c_void_p * len(scenes))(*[s._h for s in scenes])
+    check(lib().rt_render_multi(handles, len(scenes), C.byref(camera), C.byref(params), strip_rows, cb, None, hook, None),
+          "rt_render_multi")
+    return tiles
+
+
 class Scene:
     """RtScene handle: a scene uploaded to one GPU (rt_scene_create)."""
 
@@ -130,7 +149,7 @@ class Scene:
         """rt_render_frame_device: out_ptr = device address (int), stream = hipStream_t (int)."""
         check(self._lib.rt_render_frame_device(self._h, C.byref(camera), C.byref(params),
                                            C.c_void_p(out_ptr), C.c_void_p(stream or 0)),
-              "rt_render_frame_device")
+              "rt_render_frame_device", self._lib)
 
     def render_frame_rgba8(self, camera, params, tone_map):
         """rt_render_frame_rgba8 -> uint8 [H, W, 4]: render, tone-map and pack on the device."""
@@ -143,19 +162,20 @@ class Scene:
         """rt_post_rgba8_device on device addresses (ints)."""
         check(self._lib.rt_post_rgba8_device(self._h, C.byref(tone_map), C.c_void_p(rgb_ptr), n_pixels,
                                          C.c_void_p(rgba_ptr), C.c_void_p(mapped_ptr or 0), C.c_void_p(stream or 0)),
-              "rt_post_rgba8_device")
+              "rt_post_rgba8_device", self._lib)
 
     def render_tiles(self, camera, params, cancel=None):
-        """rt_render -> list of (r, c, width, height, float64 [height, width, 3])."""
+        """rt_render / rt_render_ex -> list of (r, c, width, height, float64 [height, width, 3]).
+        cancel: None, a ctypes pointer to an int flag (rt_render), or a callable returning True once the
+        render should stop (rt_render_ex's RtCancelCallback — how the reference's SignalEvent binds)."""
         tiles = []
-
-        def on_tile(_user, rgb, r, c, w, h):
-            arr = np.ctypeslib.as_array(rgb, shape=(h, w, 3)).copy()
-            tiles.append((r, c, w, h, arr))
-
-        cb = abi.RtTileCallback(on_tile)
-        cancel_ptr = C.cast(cancel, C.POINTER(C.c_int)) if cancel is not None else None
-        check(self._lib.rt_render(self._h, C.byref(camera), C.byref(params), cb, None, cancel_ptr), "rt_render", self._lib)
+        cb = abi.RtTileCallback(_tile_collector(tiles))
+        if callable(cancel):
+            hook = abi.RtCancelCallback(lambda _user: 1 if cancel() else 0)
+            check(self._lib.rt_render_ex(self._h, C.byref(camera), C.byref(params), cb, None, hook, None), "rt_render_ex", self._lib)
+        else:
+            cancel_ptr = C.cast(cancel, C.POINTER(C.c_int)) if cancel is not None else None
+            check(self._lib.rt_render(self._h, C.byref(camera), C.byref(params), cb, None, cancel_ptr), "rt_render", self._lib)
         return tiles
 
     def last_stats(self):

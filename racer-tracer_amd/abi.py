@@ -5,7 +5,7 @@ C header; tests/test_abi_layout.py checks the sizes against the C compiler.
 """
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # RtError (reference codes: racer-tracer/src/error.rs:71-97)
 RT_OK = 0
@@ -111,6 +111,8 @@ class RtSceneOptions(C.Structure):
 
 RtTileCallback = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_int32,
                              C.c_int32, C.c_int32)
+# int (*RtCancelCallback)(void *cancel_user): non-zero = stop (renderer.rs:25-30 do_cancel)
+RtCancelCallback = C.CFUNCTYPE(C.c_int, C.c_void_p)
 
 # Every symbol include/rt_abi.h declares: name -> (restype, argtypes)
 PROTOTYPES = {
@@ -125,6 +127,10 @@ PROTOTYPES = {
                                          C.POINTER(RtRenderParams), C.c_void_p, C.c_void_p]),
     "rt_render": (C.c_int, [C.c_void_p, C.POINTER(RtCamera), C.POINTER(RtRenderParams),
                             RtTileCallback, C.c_void_p, C.POINTER(C.c_int)]),
+    "rt_render_ex": (C.c_int, [C.c_void_p, C.POINTER(RtCamera), C.POINTER(RtRenderParams),
+                               RtTileCallback, C.c_void_p, RtCancelCallback, C.c_void_p]),
+    "rt_render_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(RtCamera), C.POINTER(RtRenderParams), C.c_int,
+                                  RtTileCallback, C.c_void_p, RtCancelCallback, C.c_void_p]),
     "rt_post_rgba8_device": (C.c_int, [C.c_void_p, C.POINTER(RtToneMap), C.c_void_p, C.c_size_t, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     "rt_render_frame_rgba8": (C.c_int, [C.c_void_p, C.POINTER(RtCamera), C.POINTER(RtRenderParams),

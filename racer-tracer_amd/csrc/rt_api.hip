@@ -36,9 +36,10 @@ int rtapi::fail(int code, const std::string &msg) {
     g_last_error = msg;
     return code;
 }
+using rtapi::Cancel;
+using rtapi::Delivery;
 using rtapi::DevBuf;
 using rtapi::fail;
-using rtapi::Window;
 
 
 namespace {
@@ -197,9 +198,7 @@ void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtd
         a.strip_rows = p->strip_rows;
         a.strip_count = p->strip_count;
         a.strip_index = p->strip_index;
-        int owned_strips = 0; // strips j with first row (j*count + index)*rows inside the image
-        for (long long j = 0; (j * p->strip_count + p->strip_index) * (long long)p->strip_rows < p->height; ++j) ++owned_strips;
-        a.owned_rows = owned_strips * p->strip_rows;
+        a.owned_rows = rtapi::owned_rows_of(p);
     } else {
         a.strip_rows = p->height;
         a.strip_count = 1;
@@ -265,29 +264,35 @@ void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtd
 
 } // namespace
 
+int rtapi::owned_rows_of(const RtRenderParams *p) {
+    if (p->strip_count <= 1) return p->height;
+    int owned_strips = 0; // strips j with first row (j*count + index)*rows inside the image
+    for (long long j = 0; (j * p->strip_count + p->strip_index) * (long long)p->strip_rows < p->height; ++j) ++owned_strips;
+    return owned_strips * p->strip_rows;
+}
+
 int rtapi::enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, double *out_device,
-                          hipStream_t stream, int batch, const volatile int *cancel, const Window &win) {
+                          hipStream_t stream, int batch, const Cancel &cancel, const Delivery *delivery) {
     RT_HIP(hipSetDevice(s->device));
     size_t n = (size_t)p->width * (size_t)p->height * 3;
     rtdev::TraceArgs a;
     fill_args(s, camera, p, a);
     if (batch <= 0 || batch > p->samples) batch = p->samples;
     int launches = 0;
-    const bool windowed = win.width > 0;
     if (s->use_v1) {
         if (p->scale > 1) return fail(RT_ERR_UNSUPPORTED, "the v1 kernel has no preview mode");
-        if (windowed) return fail(RT_ERR_UNSUPPORTED, "the v1 kernel has no column windows");
+        if (delivery) return fail(RT_ERR_UNSUPPORTED, "the v1 kernel does not deliver its own pixels");
         if (s->accum.count < n) RT_HIP(s->accum.alloc(n));
         a.accum = s->accum.ptr;
         RT_HIP(hipMemsetAsync(s->segments.ptr, 0, rtdev::RT_STAT_SLOTS * sizeof(unsigned long long), stream));
         RT_HIP(hipEventRecord(s->ev_begin, stream));
         for (int b = 0; b < p->samples; b += batch) {
-            if (cancel && *cancel) return RT_ERR_CANCEL_EVENT;
+            if (cancel.raised()) return RT_ERR_CANCEL_EVENT;
             a.sample_begin = b;
             a.sample_end = b + batch < p->samples ? b + batch : p->samples;
             RT_HIP(rtdev_launch_trace(&a, s->prims_class, s->textured, s->specular, stream));
             ++launches;
-            if (cancel) RT_HIP(hipStreamSynchronize(stream)); // so the next poll is meaningful
+            if (cancel.armed()) RT_HIP(hipStreamSynchronize(stream)); // so the next poll is meaningful
         }
         RT_HIP(hipEventRecord(s->ev_traced, stream));
         RT_HIP(rtdev_launch_resolve(s->accum.ptr, out_device, p->width, p->height, a.strip_rows, a.strip_count,
@@ -295,18 +300,15 @@ int rtapi::enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderPara
         RT_HIP(hipEventRecord(s->ev_resolved, stream));
     } else {
         // Work items = 8x8 tiles x sample chunks.
-        if (windowed) { // step_x == 1: rt_render never windows a preview
-            a.x_origin = win.x0;
-            a.cover_w = win.x0 + win.width;
-        }
-        a.tiles_x = ((a.cover_w - a.x_origin) / a.step_x + 7) / 8; // grid cells per row of the window
+        a.tiles_x = (a.cover_w / a.step_x + 7) / 8; // grid cells per row
         a.n_tiles = a.tiles_x * ((a.owned_rows + 7) / 8);
-        // Sample chunks (chunk_plan above).  Sample batches (cancel polling) are cut on chunk boundaries, so
-        // batching changes nothing either.
+        // Sample chunks (chunk_plan above).  Sample batches are cut on chunk boundaries, so batching changes
+        // nothing either.
         const std::vector<int> starts = chunk_plan(p->samples);
         const int total_chunks = (int)starts.size() - 1;
         for (int c = 0; c <= total_chunks; ++c) a.chunk_start[c] = starts[(size_t)c];
         a.chunk_samples = starts[1] - starts[0];
+        a.total_chunks = total_chunks;
         struct Launch {
             int first_chunk, n_chunks;
         };
@@ -319,24 +321,58 @@ int rtapi::enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderPara
             }
             plan.push_back(l);
         }
+        if (delivery) { // one launch, its items queued region by region, finishing its own pixels
+            if (plan.size() != 1 || p->scale > 1) return fail(RT_ERR_UNSUPPORTED, "a delivering launch is one whole-frame launch");
+            if (delivery->regions.empty() || (int)delivery->regions.size() > rtdev::RT_MAX_REGIONS)
+                return fail(RT_ERR_INVALID_ARGUMENT, "bad region list");
+            if (s->tile_done.count < (size_t)a.n_tiles) {
+                RT_HIP(s->tile_done.alloc((size_t)a.n_tiles));
+                s->deliver_dirty = true;
+            }
+            if (s->region_done.count < (size_t)rtdev::RT_MAX_REGIONS) {
+                RT_HIP(s->region_done.alloc((size_t)rtdev::RT_MAX_REGIONS));
+                s->deliver_dirty = true;
+            }
+            if (s->deliver_dirty) { // fresh buffers, or a launch that was cut short (cancel, error): counters back to zero
+                RT_HIP(hipMemsetAsync(s->tile_done.ptr, 0, s->tile_done.count * sizeof(unsigned int), stream));
+                RT_HIP(hipMemsetAsync(s->region_done.ptr, 0, s->region_done.count * sizeof(unsigned int), stream));
+            }
+            s->deliver_dirty = true; // until every region has been published (rt_deliver.hip clears it)
+            a.n_regions = (int)delivery->regions.size();
+            uint64_t at = 0;
+            for (int r = 0; r < a.n_regions; ++r) {
+                rtdev::Region reg = delivery->regions[(size_t)r];
+                if (reg.ntx <= 0 || reg.nty <= 0 || reg.tx0 < 0 || reg.ty0 < 0 || reg.tx0 + reg.ntx > a.tiles_x ||
+                    (reg.ty0 + reg.nty) * a.tiles_x > a.n_tiles)
+                    return fail(RT_ERR_INVALID_ARGUMENT, "region outside the tile grid");
+                reg.item_begin = (uint32_t)at;
+                at += (uint64_t)reg.ntx * (uint64_t)reg.nty * (uint64_t)total_chunks;
+                a.regions[r] = reg;
+            }
+            if (at != (uint64_t)a.n_tiles * (uint64_t)total_chunks) return fail(RT_ERR_INVALID_ARGUMENT, "the regions do not tile the grid");
+            a.deliver_out = delivery->out;
+            a.tile_done = s->tile_done.ptr;
+            a.region_done = s->region_done.ptr;
+            a.deliver_flags = s->host_flags;
+            a.deliver_serial = delivery->serial;
+            a.deliver_col_step = delivery->col_step;
+            a.deliver_cols = delivery->cols;
+        }
         const int n_batches = (int)plan.size();
         if (s->partial.count < n * (size_t)total_chunks) RT_HIP(s->partial.alloc(n * (size_t)total_chunks));
-        const size_t queue_slots = (size_t)n_batches * (size_t)win.count;
-        if (win.index == 0 && s->queue.count < queue_slots) RT_HIP(s->queue.alloc(queue_slots));
+        if (s->queue.count < (size_t)n_batches) RT_HIP(s->queue.alloc((size_t)n_batches));
         a.partial = s->partial.ptr;
-        if (win.index == 0) {
-            RT_HIP(hipMemsetAsync(s->segments.ptr, 0, rtdev::RT_STAT_SLOTS * sizeof(unsigned long long), stream));
+        RT_HIP(hipMemsetAsync(s->segments.ptr, 0, rtdev::RT_STAT_SLOTS * sizeof(unsigned long long), stream));
 #ifdef RT_PROFILE_REGIONS
-            RT_HIP(hipMemsetAsync(s->segments.ptr + rtdev::RT_STAT_WALL + 0, 0xff, sizeof(unsigned long long), stream)); // min slots
-            RT_HIP(hipMemsetAsync(s->segments.ptr + rtdev::RT_STAT_WALL + 2, 0xff, sizeof(unsigned long long), stream));
+        RT_HIP(hipMemsetAsync(s->segments.ptr + rtdev::RT_STAT_WALL + 0, 0xff, sizeof(unsigned long long), stream)); // min slots
+        RT_HIP(hipMemsetAsync(s->segments.ptr + rtdev::RT_STAT_WALL + 2, 0xff, sizeof(unsigned long long), stream));
 #endif
-            RT_HIP(hipMemsetAsync(s->queue.ptr, 0, sizeof(unsigned int) * queue_slots, stream));
-            RT_HIP(hipEventRecord(s->ev_begin, stream));
-        }
+        RT_HIP(hipMemsetAsync(s->queue.ptr, 0, sizeof(unsigned int) * s->queue.count, stream));
+        RT_HIP(hipEventRecord(s->ev_begin, stream));
         // a slice is only written for the pixels a launch covers; unowned rows are skipped by the resolve
         int chunks_done = 0;
         for (const Launch &l : plan) {
-            if (cancel && *cancel) return RT_ERR_CANCEL_EVENT;
+            if (cancel.raised()) return RT_ERR_CANCEL_EVENT;
             a.sample_begin = starts[(size_t)l.first_chunk];
             a.sample_end = starts[(size_t)(l.first_chunk + l.n_chunks)];
             a.n_chunks = l.n_chunks;
@@ -344,7 +380,7 @@ int rtapi::enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderPara
             a.n_items = (uint32_t)a.n_chunks * (uint32_t)a.n_tiles;
             if ((uint64_t)a.n_chunks * (uint64_t)a.n_tiles >= 0x40000000ull) // the item counter's top bit is the cancel poison
                 return fail(RT_ERR_UNSUPPORTED, "more than 2^30 work items in one launch");
-            a.queue = s->queue.ptr + (size_t)win.index * (size_t)n_batches + launches;
+            a.queue = s->queue.ptr + launches;
             unsigned blocks = (unsigned)(s->num_cus * (a.lens_lds ? s->pool_blocks_per_cu_lens : s->pool_blocks_per_cu));
             unsigned needed = (a.n_items + 3) / 4;
             if (blocks > needed) blocks = needed;
@@ -353,25 +389,24 @@ int rtapi::enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderPara
             ++launches;
         }
         RT_HIP(hipEventRecord(s->ev_traced, stream));
-        RT_HIP(rtdev_launch_resolve_chunks(s->partial.ptr, out_device, p->width, p->height, chunks_done, a.strip_rows,
-                                           a.strip_count, a.strip_index, a.step_x, a.step_y,
-                                           windowed ? p->width : a.cover_w, a.cover_h, win.x0, win.width, p->samples,
-                                           stream));
+        if (!delivery)
+            RT_HIP(rtdev_launch_resolve_chunks(s->partial.ptr, out_device, p->width, p->height, chunks_done, a.strip_rows,
+                                               a.strip_count, a.strip_index, a.step_x, a.step_y, a.cover_w, a.cover_h, 0,
+                                               p->width, p->samples, stream));
         RT_HIP(hipEventRecord(s->ev_resolved, stream));
         s->last_chunks = chunks_done;
     }
     s->last_stream = stream;
     s->has_stats = true;
-    s->last_launches = (win.index == 0 ? 0 : s->last_launches) + launches;
+    s->last_launches = launches;
     return RT_OK;
 }
 using rtapi::enqueue_render;
 
-namespace {
-// Block until `ev` has happened; with a cancel flag, poll it meanwhile and give up
-// (RT_ERR_CANCEL_EVENT) as soon as it is set.
-int wait_event(hipEvent_t ev, const volatile int *cancel) {
-    if (!cancel) {
+// Block until `ev` has happened; with a cancel hook, poll it meanwhile and give up
+// (RT_ERR_CANCEL_EVENT) as soon as it is raised.
+int rtapi::wait_event(hipEvent_t ev, const Cancel &cancel) {
+    if (!cancel.armed()) {
         RT_HIP(hipEventSynchronize(ev));
         return RT_OK;
     }
@@ -380,7 +415,7 @@ int wait_event(hipEvent_t ev, const volatile int *cancel) {
         if (e == hipSuccess) return RT_OK;
         if (e != hipErrorNotReady) return fail(RT_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
         (void)hipGetLastError(); // hipErrorNotReady is sticky in hipGetLastError otherwise
-        if (*cancel) return RT_ERR_CANCEL_EVENT;
+        if (cancel.raised()) return RT_ERR_CANCEL_EVENT;
         std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
 }
@@ -389,9 +424,12 @@ int wait_event(hipEvent_t ev, const volatile int *cancel) {
 // (enqueue_render keeps a launch below 2^30 items, so no count of further hand-outs wraps it).
 // The counters are written by the command processor (hipStreamWriteValue32 on a third stream): that needs
 // neither a compute unit nor a copy engine.  A 4-byte hipMemcpyAsync was measured first — the runtime runs it
-// as a kernel, which found no room beside six resident blocks per CU until the column in flight had finished
-// (50 ms instead of one item's 10).
-int poison_queue(RtScene *s) {
+// as a kernel, which found no room beside six resident blocks per CU until the work in flight had finished
+// (50 ms instead of one item's 10).  The control stream first waits for ev_begin, which the render stream records
+// BEHIND its own clearing of the counters: a cancel raised right after the enqueue cannot be erased by that memset.
+int rtapi::poison_queue(RtScene *s) {
+    RT_HIP(hipSetDevice(s->device));
+    RT_HIP(hipStreamWaitEvent(s->stream_ctl, s->ev_begin, 0));
     bool by_cp = true;
     for (size_t i = 0; i < s->queue.count && by_cp; ++i)
         by_cp = hipStreamWriteValue32(s->stream_ctl, s->queue.ptr + i, 0x80000000u, 0) == hipSuccess;
@@ -402,7 +440,6 @@ int poison_queue(RtScene *s) {
     RT_HIP(hipStreamSynchronize(s->stream_ctl));
     return RT_OK;
 }
-} // namespace
 
 extern "C" {
 
@@ -454,7 +491,6 @@ void rt_scene_destroy(RtScene *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    if (s->stream2) (void)hipStreamSynchronize(s->stream2);
     for (uint8_t *p : s->image_pixels)
         if (p) (void)hipFree(p);
     s->prims.release();
@@ -473,12 +509,11 @@ void rt_scene_destroy(RtScene *s) {
     if (s->ev_begin) (void)hipEventDestroy(s->ev_begin);
     if (s->ev_traced) (void)hipEventDestroy(s->ev_traced);
     if (s->ev_resolved) (void)hipEventDestroy(s->ev_resolved);
-    for (int k = 0; k < 2; ++k) {
-        if (s->ev_column[k]) (void)hipEventDestroy(s->ev_column[k]);
-        if (s->pinned[k]) (void)hipHostFree(s->pinned[k]);
-    }
+    s->tile_done.release();
+    s->region_done.release();
+    if (s->host_frame) (void)hipHostFree(s->host_frame);
+    if (s->host_flags) (void)hipHostFree(s->host_flags);
     if (s->stream) (void)hipStreamDestroy(s->stream);
-    if (s->stream2) (void)hipStreamDestroy(s->stream2);
     if (s->stream_ctl) (void)hipStreamDestroy(s->stream_ctl);
     delete s;
 }
@@ -719,11 +754,12 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
     RT_HIP(s->segments.alloc(rtdev::RT_STAT_SLOTS)); // rt_device_types.h: RT_STAT_*
     RT_HIP(hipMemset(s->segments.ptr, 0, rtdev::RT_STAT_SLOTS * sizeof(unsigned long long)));
     RT_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-    RT_HIP(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
     RT_HIP(hipEventCreate(&s->ev_begin));
     RT_HIP(hipEventCreate(&s->ev_traced));
     RT_HIP(hipEventCreate(&s->ev_resolved));
-    for (int k = 0; k < 2; ++k) RT_HIP(hipEventCreateWithFlags(&s->ev_column[k], hipEventDisableTiming));
+    RT_HIP(hipHostMalloc((void **)&s->host_flags, rtdev::RT_MAX_REGIONS * sizeof(unsigned int),
+                         hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
+    memset(s->host_flags, 0, rtdev::RT_MAX_REGIONS * sizeof(unsigned int));
     RT_HIP(hipStreamCreateWithFlags(&s->stream_ctl, hipStreamNonBlocking));
     guard.s = nullptr;
     *out = s;
@@ -748,199 +784,7 @@ int rt_render_frame_device(RtScene *s, const RtCamera *camera, const RtRenderPar
     if (!s || !out_dev) return fail(RT_ERR_INVALID_ARGUMENT, "scene/out is NULL");
     int rc = check_params(camera, p);
     if (rc != RT_OK) return rc;
-    return enqueue_render(s, camera, p, out_dev, (hipStream_t)hip_stream, 0, nullptr);
-}
-
-int rt_render_frame(RtScene *s, const RtCamera *camera, const RtRenderParams *p, double *out_rgb) {
-    if (!s || !out_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "scene/out is NULL");
-    int rc = check_params(camera, p);
-    if (rc != RT_OK) return rc;
-    RT_HIP(hipSetDevice(s->device));
-    size_t n = (size_t)p->width * (size_t)p->height * 3;
-    if (s->frame.count < n) RT_HIP(s->frame.alloc(n));
-    rc = enqueue_render(s, camera, p, s->frame.ptr, s->stream, 0, nullptr);
-    if (rc != RT_OK) return rc;
-    RT_HIP(hipStreamSynchronize(s->stream));
-    if (p->strip_count > 1) { // copy the owned rows only; the rest of out_rgb stays untouched
-        size_t row_bytes = (size_t)p->width * 3 * sizeof(double);
-        for (int r = 0; r < p->height; ++r)
-            if ((r / p->strip_rows) % p->strip_count == p->strip_index)
-                RT_HIP(hipMemcpy(out_rgb + (size_t)r * p->width * 3, s->frame.ptr + (size_t)r * p->width * 3,
-                                 row_bytes, hipMemcpyDeviceToHost));
-    } else {
-        RT_HIP(hipMemcpy(out_rgb, s->frame.ptr, n * sizeof(double), hipMemcpyDeviceToHost));
-    }
-    return RT_OK;
-}
-
-int rt_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, RtTileCallback callback, void *user,
-              const volatile int *cancel) {
-    if (!s || !callback) return fail(RT_ERR_INVALID_ARGUMENT, "scene/callback is NULL");
-    int rc = check_params(camera, p);
-    if (rc != RT_OK) return rc;
-    if (p->tiles_w <= 0 || p->tiles_h <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "tile grid must be positive");
-    if (p->strip_count > 1) // a tile of the stream is a finished piece of the frame; row ownership is for rt_render_frame*
-        return fail(RT_ERR_INVALID_ARGUMENT, "rt_render delivers whole tiles: strip ownership is not supported here");
-    if (cancel && *cancel) return RT_ERR_CANCEL_EVENT; // cpu.rs:82-85: prepare_threads fails with CancelEvent
-    RT_HIP(hipSetDevice(s->device));
-    const size_t n = (size_t)p->width * (size_t)p->height * 3;
-    if (s->frame.count < n) RT_HIP(s->frame.alloc(n));
-    // cpu.rs:73-115 tile grid, column-major, remainders in the last row/column
-    const int width_step = p->width / p->tiles_w, height_step = p->height / p->tiles_h;
-    auto column_x = [&](int ws) { return width_step * ws; };
-    auto column_w = [&](int ws) { return ws == p->tiles_w - 1 ? p->width - width_step * ws : width_step; };
-    // One callback per tile of tile column `ws`, top to bottom; `col` holds the column's
-    // pixels as [height][w][3], so a tile is a contiguous run of it.
-    auto emit_column = [&](int ws, const double *col) {
-        const int x = column_x(ws), w = column_w(ws);
-        for (int hs = 0; hs < p->tiles_h; ++hs) {
-            if (cancel && *cancel) return false;
-            const int y = height_step * hs;
-            const int h = hs == p->tiles_h - 1 ? p->height - y : height_step;
-            if (w <= 0 || h <= 0) continue;
-            callback(user, col + (size_t)y * (size_t)w * 3, y, x, w, h);
-        }
-        return true;
-    };
-
-    // PROGRESSIVE DELIVERY.  The reference's tiles reach the writer as they finish
-    // (cpu.rs:64-70) in roughly column-major order (the order of prepare_threads' list).
-    // Here one tile COLUMN is one unit: trace -> resolve -> copy of column k are enqueued,
-    // then the callbacks of column k-1 run on this thread while the GPU works on column k.
-    // Every pixel's value is independent of the window it was traced in (the RNG is
-    // addressed by the global pixel index, the chunk boundaries depend on spp only), so
-    // the tiles are bit-identical to rt_render_frame's.
-    //
-    // CANCEL.  The reference polls `do_cancel` per tile row (cpu.rs:55).  Here the caller's
-    // flag is polled by this thread before every launch and every callback and WHILE it
-    // waits for a column.  When it rises, poison_queue() overwrites the item counters of
-    // this call's launches (running or still queued) with 2^31 from a third stream: every
-    // wave's next hand-out then reads "no items left", so the GPU drains within one item's
-    // time.  The kernels know nothing of it, no launch is split and nothing synchronises
-    // for the flag's sake: a render with a flag costs what one without costs.  (A flag in
-    // mapped host memory that the waves read themselves was measured first: reads of it
-    // cross PCIe one by one, +17 ms on C3's 100 even at one read per 64 items.)  Tiles
-    // delivered before the flag rose stay delivered, like the reference's tiles that
-    // finished before the cancel (cpu.rs:55-62).
-    const bool progressive = !s->use_v1 && p->scale <= 1 && p->tiles_w > 1 && width_step > 0;
-    if (progressive) {
-        int widest = 0;
-        for (int ws = 0; ws < p->tiles_w; ++ws) widest = column_w(ws) > widest ? column_w(ws) : widest;
-        const size_t col_doubles = (size_t)widest * (size_t)p->height * 3;
-        for (int k = 0; k < 2; ++k)
-            if (s->pinned_count[k] < col_doubles) {
-                if (s->pinned[k]) (void)hipHostFree(s->pinned[k]);
-                s->pinned[k] = nullptr;
-                s->pinned_count[k] = 0;
-                RT_HIP(hipHostMalloc((void **)&s->pinned[k], col_doubles * sizeof(double), hipHostMallocDefault));
-                s->pinned_count[k] = col_doubles;
-            }
-        // A pixel's sum depends on the order its samples meet in LDS, i.e. on which 8x8
-        // item tile it sits in.  So the GPU windows are cut on the whole-frame tile grid:
-        // window k = [up8(x_k), up8(x_k+1)) (first from 0, last to the image edge) holds
-        // exactly the item tiles of the whole-frame render, and tile column k is complete
-        // once windows 0..k are (up8(x_k+1) >= x_k+1).  A window may be empty.
-        auto window_begin = [&](int ws) {
-            if (ws <= 0) return 0;
-            if (ws >= p->tiles_w) return p->width;
-            const int x = (column_x(ws) + 7) & ~7;
-            return x < p->width ? x : p->width;
-        };
-        bool cancelled = false;
-        bool started = false; // the first non-empty window resets the counters and records ev_begin
-        int pending = -1;     // column whose copy is in flight
-        // Columns alternate between two streams: the next column's waves fill the CUs that the previous column's last
-        // items leave idle, instead of each of the launches paying its own ramp and tail.
-        hipStream_t streams[2] = {s->stream, s->stream2};
-        auto drain = [&] {
-            (void)hipStreamSynchronize(s->stream);
-            (void)hipStreamSynchronize(s->stream2);
-        };
-        for (int ws = 0; ws < p->tiles_w && !cancelled; ++ws) {
-            hipStream_t stream = streams[ws & 1];
-            Window win;
-            win.x0 = window_begin(ws);
-            win.width = window_begin(ws + 1) - win.x0;
-            win.index = started ? ws : 0;
-            win.count = p->tiles_w;
-            if (win.width > 0) {
-                // the counters are reset and ev_begin is recorded by the first window, on ITS stream
-                if (started && stream != s->last_stream) RT_HIP(hipStreamWaitEvent(stream, s->ev_begin, 0));
-                rc = enqueue_render(s, camera, p, s->frame.ptr, stream, 0, cancel, win);
-                started = true;
-                if (rc == RT_ERR_CANCEL_EVENT) {
-                    cancelled = true;
-                    break;
-                }
-                if (rc != RT_OK) {
-                    drain();
-                    return rc;
-                }
-            }
-            const int cx = column_x(ws), cw = column_w(ws);
-            // column ws may begin with pixels of the window before it (windows are cut on the 8-pixel grid)
-            if (ws > 0) RT_HIP(hipStreamWaitEvent(stream, s->ev_column[(ws - 1) & 1], 0));
-            RT_HIP(hipMemcpy2DAsync(s->pinned[ws & 1], (size_t)cw * 3 * sizeof(double), s->frame.ptr + (size_t)cx * 3,
-                                    (size_t)p->width * 3 * sizeof(double), (size_t)cw * 3 * sizeof(double),
-                                    (size_t)p->height, hipMemcpyDeviceToHost, stream));
-            RT_HIP(hipEventRecord(s->ev_column[ws & 1], stream));
-            if (pending >= 0) { // the previous column is (or soon will be) on the host
-                rc = wait_event(s->ev_column[pending & 1], cancel);
-                if (rc == RT_ERR_CANCEL_EVENT || (rc == RT_OK && !emit_column(pending, s->pinned[pending & 1]))) {
-                    cancelled = true;
-                    break;
-                }
-                if (rc != RT_OK) {
-                    drain();
-                    return rc;
-                }
-            }
-            pending = ws;
-        }
-        if (!cancelled) {
-            rc = wait_event(s->ev_column[pending & 1], cancel);
-            if (rc == RT_OK) emit_column(pending, s->pinned[pending & 1]);
-            cancelled = rc == RT_ERR_CANCEL_EVENT;
-        }
-        if (cancelled) { // cpu.rs:55-62: Ok(()), nothing further is written
-            rc = poison_queue(s); // the waves in flight stop at their next item
-        }
-        drain(); // both streams are idle when the call returns
-        return rc;
-    }
-
-    // Whole-frame path (preview scale, a single tile column, the v1 kernel): the
-    // tiles are cut from the finished frame.  The pool kernel's waves watch the flag
-    // themselves (above); the v1 kernel is traced in sample batches with a
-    // synchronisation after each, so that its flag is polled about as often as the
-    // reference polls it per tile row (cpu.rs:55).
-    int batch = 0;
-    if (cancel && s->use_v1) { // at most 32 launches, at least 16 samples each
-        batch = (p->samples + 31) / 32;
-        if (batch < 16) batch = 16;
-        if (batch > p->samples) batch = p->samples;
-    }
-    rc = enqueue_render(s, camera, p, s->frame.ptr, s->stream, batch, cancel);
-    if (rc == RT_OK) rc = wait_event(s->ev_resolved, cancel);
-    if (rc == RT_ERR_CANCEL_EVENT) { // cpu.rs:55-62: return Ok, no tile written
-        rc = s->use_v1 ? RT_OK : poison_queue(s);
-        (void)hipStreamSynchronize(s->stream);
-        return rc;
-    }
-    if (rc != RT_OK) return rc;
-    RT_HIP(hipStreamSynchronize(s->stream));
-    std::vector<double> frame(n);
-    RT_HIP(hipMemcpy(frame.data(), s->frame.ptr, n * sizeof(double), hipMemcpyDeviceToHost));
-    std::vector<double> column;
-    for (int ws = 0; ws < p->tiles_w; ++ws) {
-        const int x = column_x(ws), w = column_w(ws);
-        if (w <= 0) continue;
-        column.resize((size_t)w * (size_t)p->height * 3);
-        for (int r = 0; r < p->height; ++r)
-            memcpy(&column[(size_t)r * w * 3], &frame[((size_t)r * p->width + x) * 3], (size_t)w * 3 * sizeof(double));
-        if (!emit_column(ws, column.data())) return RT_OK;
-    }
-    return RT_OK;
+    return enqueue_render(s, camera, p, out_dev, (hipStream_t)hip_stream, 0, Cancel());
 }
 
 int rt_post_rgba8_device(RtScene *s, const RtToneMap *tm, const double *rgb_device, size_t n_pixels,
@@ -963,7 +807,7 @@ int rt_render_frame_rgba8(RtScene *s, const RtCamera *camera, const RtRenderPara
     const size_t px = (size_t)p->width * (size_t)p->height;
     if (s->frame.count < px * 3) RT_HIP(s->frame.alloc(px * 3));
     if (s->rgba.count < px * 4) RT_HIP(s->rgba.alloc(px * 4));
-    rc = enqueue_render(s, camera, p, s->frame.ptr, s->stream, 0, nullptr);
+    rc = enqueue_render(s, camera, p, s->frame.ptr, s->stream, 0, Cancel());
     if (rc != RT_OK) return rc;
     rc = rt_post_rgba8_device(s, tm, s->frame.ptr, px, s->rgba.ptr, nullptr, s->stream);
     if (rc != RT_OK) return rc;

@@ -126,6 +126,16 @@ enum {
 };
 
 enum { RT_MAX_CHUNKS = 64 }; // a frame's samples are cut into at most this many chunks (slices of `partial`)
+enum { RT_MAX_REGIONS = 32 }; // a launch's items are queued region by region (TraceArgs.regions)
+
+// One region of a launch: a rectangle of 8x8 item tiles whose items (tile x chunk, chunk-major inside the region)
+// are queued together, so that the region's pixels are FINISHED together: a tile column of rt_render's tile stream,
+// a band of rows of rt_render_frame.  A launch with one region is the plain whole-grid, chunk-major queue.
+struct Region {
+    uint32_t item_begin; // first item of the region (regions are listed in queue order)
+    int32_t tx0, ntx;    // tile columns [tx0, tx0 + ntx)
+    int32_t ty0, nty;    // tile rows    [ty0, ty0 + nty)  (rows of the launch's OWNED-row grid)
+};
 
 // Kernel argument block (passed by value -> kernarg segment, scalar loads).
 struct TraceArgs {
@@ -166,9 +176,26 @@ struct TraceArgs {
     // Preview renderer (cpu_scaled.rs): grid cell (gx, gy) is pixel (gx*step_x, gy*step_y);
     // cover_w = grid width * step_x.  step_x = step_y = 1 and cover_w = width otherwise.
     int32_t step_x, step_y, cover_w, cover_h;
-    // Column window of a progressive render (rt_render): 8x8 tiles start at pixel column x_origin
-    // and pixels at or beyond cover_w are not traced.  0 and `width` for a whole-frame launch.
-    int32_t x_origin;
+    // Regions of the item queue (above).  n_regions <= 1: item = chunk * n_tiles + tile over the whole grid.
+    int32_t n_regions;
+    Region regions[RT_MAX_REGIONS];
+    // DELIVERY (rt_render, rt_render_frame and their multi-device forms).  When `deliver_out` is set the launch
+    // finishes its own pixels: the wave that completes the LAST chunk of a tile (tile_done, one counter per tile,
+    // re-armed to 0 by that wave) adds the tile's slices in chunk order — k_resolve_chunks_f64's arithmetic —
+    // and writes sqrt(sum / samples) straight to `deliver_out`, which may be pinned HOST memory mapped into the
+    // device: no resolve launch, no copy engine, nothing that needs a free compute unit beside the persistent
+    // grid.  Layout of deliver_out: tile columns of `deliver_col_step` pixels (the last one takes the remainder,
+    // cpu.rs:97-109), each stored as [height][column width][3] — so a tile of rt_render's stream is a contiguous
+    // run — or the plain [height][width][3] frame when deliver_cols == 1.  The wave that finishes a region's last
+    // tile (region_done) publishes `deliver_serial` in deliver_flags[region] (pinned host memory), which the
+    // calling thread polls.
+    double *deliver_out;
+    unsigned int *tile_done;      // [n_tiles of the owned-row grid], zero between launches
+    unsigned int *region_done;    // [RT_MAX_REGIONS], zero between launches
+    unsigned int *deliver_flags;  // [RT_MAX_REGIONS] in pinned host memory
+    uint32_t deliver_serial;
+    int32_t deliver_col_step, deliver_cols;
+    int32_t total_chunks;         // chunks of the frame (== n_chunks of a single-launch render)
     // BVH (scenes with more primitives than the brute-force loop is good for)
     const BvhNode *bvh_nodes;
     double bvh_root_mn[3], bvh_root_mx[3]; // the root box in f64 (padded like the node boxes)

@@ -1,15 +1,13 @@
-// rt_multi.hip — one frame on several GPUs of ONE process (include/rt_abi.h:
-// rt_render_frame_multi, rt_render_frame_multi_device).
+// rt_multi.hip — one frame on several GPUs of ONE process, collected in device 0's HBM (include/rt_abi.h:
+// rt_render_frame_multi_device; the host-output forms rt_render_frame_multi / rt_render_multi live in rt_deliver.hip).
 //
 // The reference shards a frame over its rayon pool by tile inside one
 // `CpuRenderer::render` call (racer-tracer/src/renderer/cpu.rs:118-131).  Here
 // the shards are 8-row strips, strip j -> scenes[j % n] (interleaved: cheap sky
 // rows and expensive floor rows spread evenly), every device traces its strips
 // on its own stream at the same time, and the finished strips are collected
-//   * to HOST memory by each device itself (its own PCIe link, no hop through
-//     device 0), or
-//   * to device 0's HBM by peer copies over xGMI, enqueued on the SOURCE
-//     device's stream right behind its resolve pass.
+// in device 0's HBM by peer copies over xGMI, enqueued on the SOURCE device's
+// stream right behind its resolve pass.
 // One process owns every device here, so plain peer copies (SDMA engines over
 // the xGMI links) do the gather; RCCL's rendezvous buys nothing without a
 // second process.  The multi-process form of the same gather is
@@ -54,6 +52,14 @@ int render_multi(RtScene *const *scenes, int n, const RtCamera *camera, const Rt
     const int dst_device = scenes[0]->device;
 
     std::vector<Share> shares((size_t)n);
+    // whatever way this function is left, no stream is still writing into the scenes' buffers afterwards
+    struct Drain {
+        std::vector<RtScene *> launched;
+        ~Drain() {
+            for (RtScene *s : launched)
+                if (hipSetDevice(s->device) == hipSuccess) (void)hipStreamSynchronize(s->stream);
+        }
+    } drain;
     // 1. every device starts tracing before any copy is enqueued (a copy to pageable host memory
     //    blocks the calling thread)
     for (int i = 0; i < n; ++i) {
@@ -73,11 +79,9 @@ int render_multi(RtScene *const *scenes, int n, const RtCamera *camera, const Rt
             if (sh.scene->frame.count < n_elems) RT_HIP(sh.scene->frame.alloc(n_elems));
             sh.target = sh.scene->frame.ptr;
         }
-        rc = rtapi::enqueue_render(sh.scene, camera, &sh.params, sh.target, sh.scene->stream, 0, nullptr);
-        if (rc != RT_OK) {
-            for (int j = 0; j <= i; ++j) (void)hipStreamSynchronize(scenes[j]->stream);
-            return rc;
-        }
+        rc = rtapi::enqueue_render(sh.scene, camera, &sh.params, sh.target, sh.scene->stream, 0, rtapi::Cancel());
+        drain.launched.push_back(sh.scene);
+        if (rc != RT_OK) return rc;
     }
     // 2. every device sends its own strips, behind its resolve pass on its own stream
     bool registered = false;
@@ -139,15 +143,6 @@ int render_multi(RtScene *const *scenes, int n, const RtCamera *camera, const Rt
 } // namespace
 
 extern "C" {
-
-int rt_render_frame_multi(RtScene *const *scenes, int n_scenes, const RtCamera *camera, const RtRenderParams *params,
-                          int strip_rows, double *out_rgb) {
-    try {
-        return render_multi(scenes, n_scenes, camera, params, strip_rows, out_rgb, false);
-    } catch (const std::exception &e) {
-        return fail(RT_ERR_OUT_OF_MEMORY, std::string("rt_render_frame_multi: ") + e.what());
-    }
-}
 
 int rt_render_frame_multi_device(RtScene *const *scenes, int n_scenes, const RtCamera *camera,
                                  const RtRenderParams *params, int strip_rows, double *out_rgb_device) {

@@ -38,12 +38,22 @@ template <class T> struct DevBuf {
     }
 };
 
-// Column window of a progressive render: pixel columns [x0, x0 + width) of every
-// row, `index` of `count` windows of one rt_render call (the segment counter and the
-// begin event belong to the first, the item-counter slots to all of them).
-struct Window {
-    int x0 = 0, width = 0; // width 0 = the whole frame
-    int index = 0, count = 1;
+// How a caller asks for cancellation: the flag of rt_render, the callback of rt_render_ex, or neither.
+// Polled by the calling thread only.
+struct Cancel {
+    const volatile int *flag = nullptr;
+    int (*fn)(void *) = nullptr;
+    void *user = nullptr;
+    bool armed() const { return flag != nullptr || fn != nullptr; }
+    bool raised() const { return (flag && *flag) || (fn && fn(user) != 0); }
+};
+
+// Where a launch's finished pixels go when the launch delivers them itself (TraceArgs.deliver_*; rt_deliver.hip).
+struct Delivery {
+    double *out = nullptr;              // device-visible address of the output (pinned host memory or HBM)
+    int col_step = 0, cols = 1;         // tile-column layout; cols == 1: plain [H][W][3] with col_step == width
+    std::vector<rtdev::Region> regions; // non-empty rectangles of item tiles in queue order (item_begin is filled in)
+    uint32_t serial = 0;                // value published in the scene's host_flags[region]
 };
 
 } // namespace rtapi
@@ -87,15 +97,18 @@ struct RtScene {
     rtapi::DevBuf<double> frame;  // resolved frame for the host-output entry points
     rtapi::DevBuf<uint8_t> rgba;  // packed frame of rt_render_frame_rgba8
     rtapi::DevBuf<unsigned long long> segments;
-    hipStream_t stream = nullptr; // used by rt_render_frame / rt_render
-    hipStream_t stream2 = nullptr; // rt_render: tile columns alternate between the two, so a column's ramp-up fills the CUs its predecessor's tail leaves idle
+    hipStream_t stream = nullptr; // used by the host-output entry points
     hipEvent_t ev_begin = nullptr, ev_traced = nullptr, ev_resolved = nullptr;
-    // rt_render's progressive delivery: two pinned column buffers [height][column width][3]
-    // and the events that say a column's copy has landed
-    double *pinned[2] = {nullptr, nullptr};
-    size_t pinned_count[2] = {0, 0};
-    hipEvent_t ev_column[2] = {nullptr, nullptr};
-    // rt_render's cancel: the stream whose command processor overwrites the launches' item counters (rt_api.hip: poison_queue)
+    // Delivery (rt_deliver.hip): the launch writes finished pixels straight into `host_frame` — pinned, portable host
+    // memory mapped into every device, so several scenes (devices) can fill one frame — and publishes finished regions
+    // in `host_flags`; tile_done / region_done are the device counters behind that (zero between launches).
+    double *host_frame = nullptr;
+    size_t host_frame_count = 0;
+    unsigned int *host_flags = nullptr; // [RT_MAX_REGIONS]
+    rtapi::DevBuf<unsigned int> tile_done, region_done;
+    uint32_t deliver_serial = 0;
+    bool deliver_dirty = false; // a delivering launch was cut short: the counters must be cleared before the next one
+    // cancel: the stream whose command processor overwrites the launches' item counters (rt_api.hip: poison_queue)
     hipStream_t stream_ctl = nullptr;
     hipStream_t last_stream = nullptr;
     bool has_stats = false;
@@ -104,8 +117,20 @@ struct RtScene {
 
 namespace rtapi {
 int check_params(const RtCamera *camera, const RtRenderParams *p);
-// Enqueue trace (in sample batches, polling `cancel` between them) + resolve on `stream`.
-// Returns RT_ERR_CANCEL_EVENT when cancelled (callers map that to RT_OK).
+// Enqueue trace + resolve on `stream` (two-pass path: the resolve kernel writes out_device), or — with a Delivery —
+// ONE delivering launch that finishes its own pixels (out_device is ignored).  `cancel` is polled between the
+// sample batches of the v1 kernel only.  Returns RT_ERR_CANCEL_EVENT when cancelled (callers map that to RT_OK).
 int enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, double *out_device,
-                   hipStream_t stream, int batch, const volatile int *cancel, const Window &win = Window());
+                   hipStream_t stream, int batch, const Cancel &cancel, const Delivery *delivery = nullptr);
+// Block until `ev` has happened, polling `cancel` meanwhile (RT_ERR_CANCEL_EVENT as soon as it is raised).
+int wait_event(hipEvent_t ev, const Cancel &cancel);
+// Ends the pool launches in flight on `s` early: every item counter becomes 2^31 (rt_api.hip).
+int poison_queue(RtScene *s);
+// Image row of row `vr` of the launch's owned-row grid (identity without strips).
+inline int owned_row_to_image_row(const RtRenderParams *p, int vr) {
+    if (p->strip_count <= 1) return vr;
+    return ((vr / p->strip_rows) * p->strip_count + p->strip_index) * p->strip_rows + vr % p->strip_rows;
+}
+// Rows of the owned-row grid of a render with these parameters (a multiple of strip_rows with strips).
+int owned_rows_of(const RtRenderParams *p);
 } // namespace rtapi

@@ -78,7 +78,8 @@
 #define RT_OCC_ANY 4 // untextured linear-loop variants with any primitive kind
 #endif
 #ifndef RT_OCC_PLAIN
-#define RT_OCC_PLAIN 5 // rects-only / spheres-only, no textures, no specular materials: 79 VGPRs, so six blocks per CU fit when LDS allows
+#define RT_OCC_PLAIN 6 // rects-only / spheres-only, no textures, no specular materials: 80 VGPRs, six blocks per CU when LDS allows (the bound is what keeps
+                       // the allocator there: with 5 it drifts to 81-89 whenever the code around the path loop changes, and the sixth block is worth 4 %)
 #endif
 namespace rtdev {
 
@@ -344,6 +345,95 @@ __device__ __forceinline__ double coop_noise_turbulence(bool need, d3 p, int dep
     return turb;
 }
 
+// DELIVERY: what a delivering launch does at the end of an item (rt_device_types.h: TraceArgs.deliver_out).  Out of
+// line on purpose: inlined, its address arithmetic and loads raised the register count of the whole path loop
+// (80 -> 89 VGPRs in the plain variants, i.e. five blocks per CU instead of six).
+__device__ __noinline__ void deliver_item(const RT_CONSTANT TraceArgs *K_in, double sum0, double sum1, double sum2, bool my_valid, int chunk,
+                                          int tx, int ty, int tile_py0, bool rows_aligned, int region, uint32_t reg_tiles) {
+    const int lane = threadIdx.x & 63;
+    const RT_CONSTANT TraceArgs *K;
+    // K: the launch's own argument block in the kernarg segment, handed in by the kernel (a by-reference copy of `A` would
+    // live in scratch, and llvm.amdgcn.kernarg.segment.ptr is NULL outside a kernel).  Function arguments travel in
+    // VGPRs; readfirstlane tells the backend that this one is wave-uniform, so its fields come by scalar loads.
+    {
+        const uint64_t bits = (uint64_t)K_in;
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bits);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bits >> 32));
+        K = (const RT_CONSTANT TraceArgs *)(((uint64_t)hi << 32) | lo);
+    }
+    chunk = __builtin_amdgcn_readfirstlane(chunk);
+    tx = __builtin_amdgcn_readfirstlane(tx);
+    ty = __builtin_amdgcn_readfirstlane(ty);
+    tile_py0 = __builtin_amdgcn_readfirstlane(tile_py0);
+    region = __builtin_amdgcn_readfirstlane(region);
+    reg_tiles = (uint32_t)__builtin_amdgcn_readfirstlane((int)reg_tiles);
+    {
+        const size_t slice = (size_t)K->height * (size_t)K->width * 3;
+        // (pixel coordinates are formed again here rather than kept in registers across the path loop)
+        const int out_px = (tx * 8 + (lane & 7)) * K->step_x;
+        int out_py = tile_py0 + (lane >> 3) * K->step_y;
+        if (!rows_aligned) {
+            const int vrow = ty * 8 + (lane >> 3);
+            out_py = ((vrow / K->strip_rows) * K->strip_count + K->strip_index) * K->strip_rows + vrow % K->strip_rows;
+        }
+        double *dst = K->partial + (size_t)(K->chunk_base + chunk) * slice + ((size_t)out_py * (size_t)K->width + (size_t)out_px) * 3;
+        // ---- DELIVERY: the launch finishes its own pixels (rt_device_types.h: TraceArgs.deliver_out).
+        // The slices cross waves inside ONE launch here, and an XCD's L2 is not coherent with its seven neighbours':
+        // a device-scope release fence per item (L2 write-back + invalidate) was measured first and costs C2 12 %
+        // (profiles/r03_fence_probe.txt).  Instead the slice stores and loads are device-scope relaxed atomics —
+        // plain stores / loads with the sc1 bit, which write through to / read from the level all XCDs share — and
+        // s_waitcnt orders this wave's stores before its bump of the tile's counter: no cache maintenance at all.
+        if (my_valid) {
+            __hip_atomic_store(dst + 0, sum0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 1, sum1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 2, sum2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the stores have been acknowledged at device scope
+        const int tile_id = ty * K->tiles_x + tx;
+        uint32_t chunks_before = 0;
+        if (lane == 0) chunks_before = __hip_atomic_fetch_add(K->tile_done + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        chunks_before = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunks_before);
+        if ((int)chunks_before != K->total_chunks - 1) return;
+        // Every chunk of this tile has landed: vec3.rs:119-125 scale_sqrt over the slices in chunk order —
+        // exactly k_resolve_chunks_f64's sum, so the pixels are bit-identical to the two-pass path.
+        if (my_valid) {
+            const double *src = K->partial + ((size_t)out_py * (size_t)K->width + (size_t)out_px) * 3;
+            double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+#pragma unroll 1
+            for (int c = 0; c < K->total_chunks; ++c) {
+                acc0 += __hip_atomic_load(src + (size_t)c * slice + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                acc1 += __hip_atomic_load(src + (size_t)c * slice + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                acc2 += __hip_atomic_load(src + (size_t)c * slice + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const double scale = 1.0 / (double)K->samples; // what rtdev_launch_resolve_chunks passes
+            // tile-column layout of the output (one column = the plain frame): column `col` starts at pixel column
+            // col * step and is stored as [height][its width][3] behind the columns before it
+            int col = out_px / K->deliver_col_step;
+            if (col > K->deliver_cols - 1) col = K->deliver_cols - 1;
+            const int col_x = col * K->deliver_col_step;
+            const int col_w = col == K->deliver_cols - 1 ? K->width - col_x : K->deliver_col_step;
+            double *out = K->deliver_out + ((size_t)K->height * (size_t)col_x + (size_t)out_py * (size_t)col_w + (size_t)(out_px - col_x)) * 3;
+            out[0] = sqrt(scale * acc0);
+            out[1] = sqrt(scale * acc1);
+            out[2] = sqrt(scale * acc2);
+        }
+        if (lane == 0) K->tile_done[tile_id] = 0u; // re-armed for the next launch on this scene
+        // The pixels may sit in HOST memory: release them at system scope before this tile is counted (once per
+        // tile, 1/19 of the items on C3), and publish the region behind an acquire of the other waves' releases.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        uint32_t tiles_before = 0;
+        if (lane == 0) tiles_before = __hip_atomic_fetch_add(K->region_done + region, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tiles_before = (uint32_t)__builtin_amdgcn_readfirstlane((int)tiles_before);
+        if (tiles_before == reg_tiles - 1u) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (lane == 0) {
+                K->region_done[region] = 0u;
+                __hip_atomic_store(K->deliver_flags + region, K->deliver_serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+}
+
 // BVH: closest hit through the skip-link hierarchy instead of the linear loop
 // (instantiated for PRIMS_ANY only; chosen for scenes with many primitives).
 template <int PRIMS, bool TEXTURED, bool SPECULAR, bool BVH>
@@ -428,10 +518,22 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
         if (lane == 0) item = atomicAdd(A.queue, 1u);
         item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
         if (item >= A.n_items) break;
-        const uint32_t chunk = item / (uint32_t)A.n_tiles;
-        const uint32_t tile = item - chunk * (uint32_t)A.n_tiles;
-        const int ty = (int)(tile / (uint32_t)A.tiles_x);
-        const int tx = (int)tile - ty * A.tiles_x;
+        // item -> (region, chunk, tile): regions in queue order, chunk-major inside a region (rt_device_types.h: Region)
+        int region = 0, reg_tx0 = 0, reg_ty0 = 0, reg_ntx = A.tiles_x;
+        uint32_t reg_tiles = (uint32_t)A.n_tiles, local = item;
+        if (A.n_regions > 1) {
+            const RT_CONSTANT TraceArgs *K = kernargs_here();
+            while (region + 1 < A.n_regions && item >= K->regions[region + 1].item_begin) ++region;
+            local = item - K->regions[region].item_begin;
+            reg_tx0 = K->regions[region].tx0;
+            reg_ntx = K->regions[region].ntx;
+            reg_ty0 = K->regions[region].ty0;
+            reg_tiles = (uint32_t)reg_ntx * (uint32_t)K->regions[region].nty;
+        }
+        const uint32_t chunk = local / reg_tiles;
+        const uint32_t tile = local - chunk * reg_tiles;
+        const int ty = reg_ty0 + (int)(tile / (uint32_t)reg_ntx);
+        const int tx = reg_tx0 + (int)(tile % (uint32_t)reg_ntx);
         int smp0, n_smp; // the chunk's samples (chunk = index within this launch)
         {
             const RT_CONSTANT TraceArgs *K = kernargs_here();
@@ -451,7 +553,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
             const int q = (ty * 8) / A.strip_rows; // wave-uniform
             tile_py0 = (q * A.strip_count + A.strip_index) * A.strip_rows + (ty * 8 - q * A.strip_rows);
         }
-        const int my_px = A.x_origin + (tx * 8 + (lane & 7)) * A.step_x;
+        const int my_px = (tx * 8 + (lane & 7)) * A.step_x;
         const int my_vrow = ty * 8 + (lane >> 3);
         int my_py = tile_py0 + (lane >> 3) * A.step_y;
         if (!rows_aligned)
@@ -486,7 +588,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                 s_off = (int)(w / (uint32_t)n_valid);
                 pix_out = L.pix_of[w - (uint32_t)s_off * (uint32_t)n_valid];
             }
-            const int px = A.x_origin + (tx * 8 + (pix_out & 7)) * A.step_x;
+            const int px = (tx * 8 + (pix_out & 7)) * A.step_x;
             py_out = tile_py0 + (pix_out >> 3) * A.step_y;
             if (!rows_aligned) {
                 const int vrow = ty * 8 + (pix_out >> 3);
@@ -841,11 +943,15 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
 
         RT_REGION(6); // scatter + accumulate (tail of the last iteration)
         // ---- item done: its sums go to its own slice of `partial`
-        if (my_valid) {
-            double *dst = A.partial + ((size_t)(A.chunk_base + (int)chunk) * (size_t)A.height * (size_t)A.width + (size_t)my_pixel) * 3;
-            dst[0] = L.sum[lane][0];
-            dst[1] = L.sum[lane][1];
-            dst[2] = L.sum[lane][2];
+        if (A.deliver_out == nullptr) {
+            if (my_valid) {
+                double *dst = A.partial + ((size_t)(A.chunk_base + (int)chunk) * (size_t)A.height * (size_t)A.width + (size_t)my_pixel) * 3;
+                dst[0] = L.sum[lane][0];
+                dst[1] = L.sum[lane][1];
+                dst[2] = L.sum[lane][2];
+            }
+        } else {
+            deliver_item(kernargs_here(), L.sum[lane][0], L.sum[lane][1], L.sum[lane][2], my_valid, (int)chunk, tx, ty, tile_py0, rows_aligned, region, reg_tiles);
         }
     }
 

@@ -14,14 +14,18 @@ import torch
 
 
 class StripGather:
-    def __init__(self, height, width, strip_rows, world, rank, device, dist=None):
+    def __init__(self, height, width, strip_rows, world, rank, device, dist=None, always_collective=False):
+        """always_collective: go through dist.gather even when world == 1 (a one-rank process group: what
+        `bench.py --force-dist` uses to prove on a one-GPU box that RCCL loads, initialises and gathers f64
+        device tensors before a multi-GPU node meets this code)."""
         self.h, self.w, self.rows = height, width, strip_rows
         self.world, self.rank, self.dist = world, rank, dist
+        self.collective = world > 1 or (always_collective and dist is not None)
         self.n_strips = (height + strip_rows - 1) // strip_rows
         self.per_rank = (self.n_strips + world - 1) // world  # padded so every rank sends the same size
         self.pad_rows = self.per_rank * world * strip_rows    # a whole number of strips for every rank
         self.padded = None
-        if world > 1:
+        if self.collective:
             kw = dict(dtype=torch.float64, device=device)
             # strip j = slot (j // world, j % world): one strided view per rank, one permute for all of them
             self.padded = torch.zeros((self.pad_rows, width, 3), **kw)
@@ -34,7 +38,7 @@ class StripGather:
         gather() moves nothing but the strips themselves.  (Any other [H, W, 3] tensor works
         too, at the price of one copy in and one out.)"""
         if self.padded is None:
-            raise RuntimeError("StripGather.frame() is only meaningful for world > 1")
+            raise RuntimeError("StripGather.frame() is only meaningful when a collective runs (world > 1)")
         return self.padded[: self.h]
 
     def owned(self, rank=None):
@@ -48,10 +52,10 @@ class StripGather:
 
     def gather(self, frame):
         """frame: [H, W, 3] float64 holding this rank's rows.  After the call
-        rank 0's frame holds every row.  No-op for world == 1.
+        rank 0's frame holds every row.  No-op for world == 1 (unless always_collective).
         Per step: one strided copy into the send buffer, ONE collective, and on rank 0 one
         permuting copy back into the frame."""
-        if self.world == 1:
+        if not self.collective:
             return frame
         own_storage = frame.data_ptr() == self.padded.data_ptr()
         if not own_storage:

@@ -1,0 +1,208 @@
+"""The delivering launch (racer-tracer_amd/csrc/rt_deliver.hip): rt_render_frame, rt_render, rt_render_ex and the
+several-device forms finish their own pixels inside ONE persistent launch and write them straight into pinned host
+memory.  Everything here is a bit-for-bit comparison against the two-pass path (trace + resolve kernel into device
+memory: rt_render_frame_device, what bench.py times), which the parity tests hold against the oracle.
+
+Reference behaviour being replaced: CpuRenderer::render's tile stream (renderer/cpu.rs:64-70,118-131) and its cancel
+hook `do_cancel` (renderer.rs:25-30), a `SignalEvent::wait_timeout(0)` poll — bound here by rt_render_ex's callback."""
+import ctypes as C
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import scenes_py as S
+
+pytestmark = pytest.mark.gpu
+
+
+def two_pass_frame(scene, camera, params):
+    """rt_render_frame_device into a torch buffer: trace kernel + resolve kernel, no delivery."""
+    import torch
+    out = torch.zeros((params.height, params.width, 3), dtype=torch.float64, device="cuda")
+    scene.render_frame_device(camera, params, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("scene_name,w,h,spp", [("cornell_box", 200, 120, 40), ("three_balls", 203, 117, 24),
+                                                 ("noise_and_textures", 160, 90, 16), ("cornell_box_boxes", 96, 54, 300)])
+def test_delivered_frame_is_the_two_pass_frame(rt, gpu, scene_name, w, h, spp):
+    if scene_name == "noise_and_textures":  # textures come through the YAML loader (Perlin table, earth map); 16:9 like its config
+        import importlib
+        import os
+        host = importlib.import_module("racer-tracer_amd.host")
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        bundle = host.Session(os.path.join(root, "scenes", "config_c4.yml"), scene=os.path.join(root, "scenes", "noise_and_textures.yml"))
+        camera = bundle.camera
+    else:
+        bundle, cam, _ = getattr(S, scene_name)()
+        camera = S.camera_for(cam, w, h)
+    params = S.abi.render_params(w, h, spp)
+    scene = rt.Scene(bundle)
+    try:
+        want = two_pass_frame(scene, camera, params)
+        segs = scene.last_stats().segments
+        for _ in range(3):  # the counters re-arm themselves: every call must deliver every pixel again
+            got = scene.render_frame(camera, params)
+            assert np.array_equal(got, want)
+            assert scene.last_stats().segments == segs
+        # strips: owned rows only, the rest untouched
+        for count, rows in ((2, 8), (3, 16), (5, 8)):
+            acc = np.full_like(want, -1.0)
+            for idx in range(count):
+                p = S.abi.render_params(w, h, spp, strip_rows=rows, strip_count=count, strip_index=idx)
+                part = scene.render_frame(camera, p)
+                own = ((np.arange(h) // rows) % count) == idx
+                assert (part[~own] == 0).all()
+                acc[own] = part[own]
+            assert np.array_equal(acc, want)
+    finally:
+        scene.close()
+
+
+def test_delivery_at_full_size_many_chunks(rt, gpu):
+    """BASELINE config 3's frame at 256 spp (16 chunks + taper): 32 400 item tiles, each finished by whichever wave
+    lands its last chunk — across all eight XCDs, whose L2s are not coherent with each other."""
+    bundle, cam, _ = S.cornell_box()
+    w, h, spp = 1920, 1080, 256
+    camera = S.camera_for(cam, w, h)
+    params = S.abi.render_params(w, h, spp)
+    scene = rt.Scene(bundle)
+    try:
+        want = two_pass_frame(scene, camera, params)
+        for _ in range(2):
+            assert np.array_equal(scene.render_frame(camera, params), want)
+        tiles = scene.render_tiles(camera, params)
+        assert len(tiles) == 100
+        stitched = np.full_like(want, -1.0)
+        for r, c, tw, th, arr in tiles:
+            stitched[r:r + th, c:c + tw] = arr
+        assert np.array_equal(stitched, want)
+    finally:
+        scene.close()
+
+
+@pytest.mark.parametrize("w,h,tw,th", [(100, 45, 40, 3), (333, 64, 64, 2), (64, 36, 33, 1)])
+def test_more_tile_columns_than_regions(rt, gpu, w, h, tw, th):
+    """A launch queues at most 32 regions: wider tile grids share regions, the tiles stay cpu.rs:73-115's."""
+    bundle, cam, _ = S.cornell_box_boxes()
+    camera = S.camera_for(cam, w, h)
+    params = S.abi.render_params(w, h, 12, tiles_w=tw, tiles_h=th)
+    scene = rt.Scene(bundle)
+    try:
+        frame = two_pass_frame(scene, camera, params)
+        tiles = scene.render_tiles(camera, params)
+    finally:
+        scene.close()
+    ws_step, hs_step = w // tw, h // th
+    expect = [(hs_step * hs, ws_step * ws, w - ws_step * ws if ws == tw - 1 else ws_step, h - hs_step * hs if hs == th - 1 else hs_step)
+              for ws in range(tw) for hs in range(th)]
+    assert [t[:4] for t in tiles] == expect
+    stitched = np.full_like(frame, -1.0)
+    for r, c, tile_w, tile_h, arr in tiles:
+        stitched[r:r + tile_h, c:c + tile_w] = arr
+    assert np.array_equal(stitched, frame)
+
+
+def test_cancel_callback_binds_like_do_cancel(rt, gpu):
+    """rt_render_ex: the cancel hook is a FUNCTION (renderer.rs:25-30 polls SignalEvent::wait_timeout(0)); a
+    threading.Event stands in for the SignalEvent.  Never raised: all tiles.  Raised mid-render: RT_OK, a prefix
+    of the tile list, the GPU drained within an item's time; raised on entry: RT_ERR_CANCEL_EVENT (cpu.rs:82-85)."""
+    bundle, cam, _ = S.cornell_box()
+    w, h = 1920, 1080
+    camera = S.camera_for(cam, w, h)
+    scene = rt.Scene(bundle)
+    try:
+        event = threading.Event()
+        polls = []
+
+        def cancelled():
+            polls.append(1)
+            return event.is_set()
+
+        quick = S.abi.render_params(w, h, 16)
+        tiles = scene.render_tiles(camera, quick, cancel=cancelled)
+        assert len(tiles) == 100 and len(polls) >= 100            # polled before every tile at least
+        want = two_pass_frame(scene, camera, quick)
+        for r, c, tw, th, arr in tiles:
+            assert np.array_equal(arr, want[r:r + th, c:c + tw])
+
+        long_render = S.abi.render_params(w, h, 8192)               # ~0.65 s of GPU work
+        raised = []
+
+        def raise_it():
+            raised.append(time.time())
+            event.set()
+
+        timer = threading.Timer(0.05, raise_it)
+        timer.start()
+        tiles = scene.render_tiles(camera, long_render, cancel=cancelled)
+        returned = time.time()
+        timer.join()
+        assert len(tiles) < 100
+        expect = [(108 * hs, 192 * ws) for ws in range(10) for hs in range(10)]
+        assert [(t[0], t[1]) for t in tiles] == expect[:len(tiles)]
+        print("rt_render_ex returned %.1f ms after the event was set" % ((returned - raised[0]) * 1e3))
+        assert returned - raised[0] < 0.25                          # one item = 512 samples of a tile: ~13 ms
+        with pytest.raises(rt.RtError) as e:
+            scene.render_tiles(camera, quick, cancel=cancelled)     # still set
+        assert e.value.code == S.abi.RT_ERR_CANCEL_EVENT
+        event.clear()                                               # the scene is reusable: counters were cleared
+        assert np.array_equal(scene.render_frame(camera, quick), want)
+    finally:
+        scene.close()
+
+
+def test_tile_stream_over_several_scenes_on_one_card(rt, gpu):
+    """rt_render_multi with 1, 2 and 3 shares on device 0 (a device may be listed twice): every share traces its
+    interleaved 8-row strips, all of them write into ONE pinned frame, and a tile column is handed over once every
+    share has published it.  Same tiles, same order, same pixels as rt_render; cancel works the same."""
+    bundle, cam, _ = S.three_balls()
+    w, h, spp = 330, 200, 24
+    camera = S.camera_for(cam, w, h)
+    params = S.abi.render_params(w, h, spp, tiles_w=7, tiles_h=3)
+    scenes = [rt.Scene(bundle) for _ in range(3)]
+    try:
+        want_tiles = scenes[0].render_tiles(camera, params)
+        for n in (1, 2, 3):
+            tiles = rt.render_tiles_multi(scenes[:n], camera, params)
+            assert [t[:4] for t in tiles] == [t[:4] for t in want_tiles]
+            for got, want in zip(tiles, want_tiles):
+                assert np.array_equal(got[4], want[4])
+            total = sum(int(s.last_stats().samples) for s in scenes[:n])
+            assert total == w * h * spp
+        big = S.abi.render_params(1920, 1080, 4096, tiles_w=10, tiles_h=10)
+        big_cam = S.camera_for(cam, 1920, 1080)
+        event = threading.Event()
+        timer = threading.Timer(0.05, event.set)
+        timer.start()
+        t0 = time.time()
+        tiles = rt.render_tiles_multi(scenes[:2], big_cam, big, cancel=event.is_set)
+        timer.join()
+        assert len(tiles) < 100 and time.time() - t0 < 0.5
+        after = rt.render_tiles_multi(scenes[:2], camera, params)
+        for got, want in zip(after, want_tiles):
+            assert np.array_equal(got[4], want[4])
+        with pytest.raises(rt.RtError):
+            rt.render_tiles_multi([scenes[0], scenes[0]], camera, params)   # the same scene twice
+    finally:
+        for s in scenes:
+            s.close()
+
+
+def test_whole_frame_over_several_scenes_matches(rt, gpu):
+    bundle, cam, _ = S.cornell_box()
+    w, h, spp = 320, 180, 48
+    camera = S.camera_for(cam, w, h)
+    params = S.abi.render_params(w, h, spp)
+    scenes = [rt.Scene(bundle) for _ in range(3)]
+    try:
+        want = two_pass_frame(scenes[0], camera, params)
+        for n in (1, 2, 3):
+            for rows in (0, 16):
+                assert np.array_equal(rt.render_frame_multi(scenes[:n], camera, params, strip_rows=rows), want)
+    finally:
+        for s in scenes:
+            s.close()

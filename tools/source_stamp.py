@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""SHA-256 over the sources the device kernels are built from.
+"""SHA-256 over the CODE of the sources the device kernels are built from — comments and white space excluded.
 
-A PMC summary under profiles/ is only evidence for the kernel it was collected
-on: tools/gpu_pmc.sh stores this stamp next to the counters, and bench.py prints
-the counter-derived roofline figures only when the stamp still matches the
-sources in the tree (otherwise it prints null and says why).
+A PMC summary under profiles/ is only evidence for the kernel it was collected on: tools/pmc.py stores this stamp next
+to the counters, and bench.py uses a committed summary only while the stamp still matches the sources in the tree.
+Comments and layout do not reach the code object, so they do not reach the stamp either (round 2 re-collected counters
+forty times for comment edits).
 """
 import hashlib
 import os
@@ -20,13 +20,39 @@ def kernel_source_files():
     return files
 
 
+def strip_comments(text):
+    """C/C++ source without // and /* */ comments (string and character literals are respected), every run of white
+    space collapsed to one blank."""
+    out = []
+    i, n = 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '"' or c == "'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c)
+            i += 1
+    return " ".join("".join(out).split())
+
+
 def kernel_source_sha():
     h = hashlib.sha256()
     for path in kernel_source_files():
         h.update(os.path.relpath(path, ROOT).encode())
         h.update(b"\0")
-        with open(path, "rb") as f:
-            h.update(f.read())
+        with open(path, "r", encoding="utf-8") as f:
+            h.update(strip_comments(f.read()).encode())
         h.update(b"\0")
     return h.hexdigest()
 
