@@ -5,8 +5,9 @@
 
 A "step" is one full render of the workload frame: rt_render_frame_device on
 this rank's row strips (+ the RCCL gather of finished strips to rank 0 when
-N > 1).  Scene, camera and output buffer are resident in HBM before the timed
-region starts.  Rank 0 prints ONE JSON line.
+N > 1) and the tone-map + RGBA8 pass over the finished frame (SURVEY 8(d):
+"resolve/tone-map kernel included").  Scene, camera and output buffers are
+resident in HBM before the timed region starts.  Rank 0 prints ONE JSON line.
 
 Default workload = BASELINE.json configs[2] (cornell_box.yml, 1920x1080, 1024
 spp, max_depth 20, Aces): it is the configuration the north star's target is
@@ -21,10 +22,20 @@ WORLD_SIZE in the environment) this process is one rank; started plainly
 touching the GPU, relays rank 0's JSON line and exits with their status.
 
 roofline: the trace kernel keeps ray state in registers, so HBM is not what
-bounds it; the bound reported is VALU issue (SIMD cycles with a vector
-instruction executing, from rocprofv3 SQ counters of the same workload under
-profiles/, used only while their source stamp matches the kernel sources in the
-tree).  SURVEY 8(d)'s algorithmic-bytes figure is kept as `hbm_algorithmic`.
+bounds it; the bound is the vector ALU.  `frac` = counted f64 FLOP per second /
+the 78.6 TFLOP/s f64 vector peak, `issue_frac` = sum over instruction classes of
+count x the class's minimum issue cost / the SIMD cycles of the launch — two
+numbers that cannot exceed 1.  The counters are collected LIVE: before this
+process touches the GPU it runs rocprofv3 --pmc passes over itself (tools/pmc.py,
+one pass per counter group, about ten seconds each); `--pmc file` uses the
+committed summary under profiles/ instead (only while its source stamp matches
+the tree), `--pmc none` skips counters.  SURVEY 8(d)'s algorithmic-bytes figure
+is kept as `hbm_algorithmic`.
+
+Also in the line: `host_delivered` — W*H*spp over the wall time of rt_render
+with the reference's 10x10 tile grid (every tile copied out of the callback),
+and of rt_render_frame into a caller-owned host frame: what a binding of the
+reference receives, next to the device-resident `value`.
 """
 import argparse
 import importlib
@@ -42,11 +53,17 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from source_stamp import kernel_source_sha  # noqa: E402
 
 STRIP_ROWS = 8
-PMC_ROUND = "r02"              # profiles/<round>_<workload>_pmc_summary.json
+PMC_ROUND = "r03"              # profiles/<round>_<workload>_pmc_summary.json
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 SIMDS = 256 * 4                # 256 CUs x 4 SIMDs
 CLOCK_GHZ = 2.4                # MI355X_MICROARCH.md peak engine clock
+F64_VECTOR_PEAK_TFLOPS = 78.6  # half the 157.3 TFLOP/s f32 vector peak (MI355X_MICROARCH.md): 1024 SIMDs x 16 lanes x 2 x 2.4 GHz
 BYTES_PER_SEGMENT_F64 = 192.0  # 96-B f64 ray record read + written per segment
+# Minimum SIMD cycles one wave instruction of a class holds its SIMD's vector issue (CDNA4: a SIMD executes 32 lanes
+# of 32-bit or 16 lanes of 64-bit work per cycle; measured per instruction in profiles/r02_valu_cost.txt: f64
+# add/mul/fma 4.2, v_rcp/rsq/sqrt_f64 16.1, plain 32-bit VOP2 2.3, 32-bit multiplies and v_mad_u64_u32 4.2-4.3,
+# conversions 4.1-4.2).  The floor of each class is used, so the sum cannot exceed the cycles that exist.
+ISSUE_COST = {"f64": 4.0, "trans_f64": 16.0, "f32": 2.0, "trans_f32": 8.0, "int32": 2.0, "int64": 4.0, "cvt": 4.0, "other": 2.0}
 
 
 def parse():
@@ -54,14 +71,22 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5", "random", "boxes", "emissive"])
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--pmc", default="live", choices=["live", "file", "none"],
+                    help="where the roofline's counters come from: rocprofv3 passes over this command run now (live), "
+                         "the committed profiles/ summary (file), or nowhere (none)")
+    ap.add_argument("--pmc-child", action="store_true", help="internal: one short run under rocprofv3 (tools/pmc.py)")
+    ap.add_argument("--no-host-delivery", action="store_true", help="skip the rt_render / rt_render_frame host timings")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group and run the strip gather as a collective even with "
                          "ONE rank (proves librccl + an f64 device gather on a one-GPU box)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.pmc_child:
+        args.steps, args.warmup, args.no_cpu_baseline, args.pmc, args.no_host_delivery = 1, 1, True, "none", True
+    return args
 
 
 def load_workload(host, name, spp_override):
@@ -70,10 +95,16 @@ def load_workload(host, name, spp_override):
         "c3": ("cornell_box.yml", "config_c3.yml"),
         "c4": ("noise_and_textures.yml", "config_c4.yml"),
         "c5": ("cornell_box.yml", "config_c5.yml"),   # configs[4]: 3840x2160x4096, meant for 8 GPUs
+        # not BASELINE configs: the other kernel variants at 1080p, for counters and profiles
+        "random": ("random", "config_c2.yml", 64),                 # 485 spheres, BVH variant
+        "boxes": ("cornell_box_boxes.yml", "config_c3.yml", 128),  # PRIMS_ANY linear loop
+        "emissive": ("emissive.yml", "config_c2.yml", 128),        # PRIMS_ANY + Noise
     }
-    scene_file, config_file = table[name]
-    session = host.Session(os.path.join(ROOT, "scenes", config_file),
-                           scene=os.path.join(ROOT, "scenes", scene_file))
+    scene_file, config_file = table[name][:2]
+    scene_arg = scene_file if scene_file == "random" else os.path.join(ROOT, "scenes", scene_file)
+    session = host.Session(os.path.join(ROOT, "scenes", config_file), scene=scene_arg)
+    if len(table[name]) > 2:
+        session.params.samples = table[name][2]
     if spp_override:
         session.params.samples = spp_override
     return session, "%s %dx%d %dspp max_depth %d" % (
@@ -123,52 +154,99 @@ def cpu_baseline(session, seconds):
                       % (p.width, p.height, spp, dt, segs / n)}
 
 
-def pmc_summary(workload, workload_name, world):
-    """The committed rocprofv3 PMC summary of this workload's trace kernel (tools/gpu_pmc.sh ->
-    profiles/<round>_<workload>_pmc_summary.json), or (None, reason).  Refused when it was collected
-    on other kernel sources than the ones in the tree, on another frame, or for N > 1."""
+def trace_kernel_counters(summary, workload_name, origin):
+    """The trace kernel's counters out of a tools/pmc.py summary, or (None, reason)."""
+    stamp = summary.get("_stamp", {})
+    if stamp.get("source_sha") != kernel_source_sha():
+        return None, "%s was collected on other kernel sources (stamp mismatch): re-run tools/pmc.py" % origin
+    if stamp.get("workload") != workload_name:
+        return None, "%s is for %r" % (origin, stamp.get("workload"))
+    kernels = [k for k in summary if "k_trace_pool_f64" in k]
+    if len(kernels) != 1:
+        return None, "%s holds %d trace kernels" % (origin, len(kernels))
+    c = dict(summary[kernels[0]], _origin=origin, _stamp=stamp, _kernel=kernels[0])
+    for need in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU"):
+        if need not in c:
+            return None, "%s lacks %s (%s)" % (origin, need, "; ".join(stamp.get("errors", [])) or "pass missing")
+    return c, None
+
+
+def committed_pmc_summary(workload, workload_name):
+    """profiles/<round>_<workload>_pmc_summary.json (tools/pmc.py), refused when it was collected on other kernel
+    sources than the ones in the tree or on another frame."""
     path = os.path.join(ROOT, "profiles", "%s_%s_pmc_summary.json" % (PMC_ROUND, workload))
     rel = os.path.relpath(path, ROOT)
-    if world != 1:
-        return None, "PMC passes are single-GPU"
     if not os.path.exists(path):
         return None, "no %s" % rel
     with open(path) as f:
-        summary = json.load(f)
-    stamp = summary.get("_stamp", {})
-    if stamp.get("source_sha") != kernel_source_sha():
-        return None, "%s was collected on other kernel sources (stamp mismatch): re-run tools/gpu_pmc.sh" % rel
-    if stamp.get("workload") != workload_name:
-        return None, "%s is for %r" % (rel, stamp.get("workload"))
-    kernels = [k for k in summary if "k_trace_pool_f64" in k]
-    if len(kernels) != 1:
-        return None, "%s holds %d trace kernels" % (rel, len(kernels))
-    return dict(summary[kernels[0]], _path=rel, _stamp=stamp), None
+        return trace_kernel_counters(json.load(f), workload_name, rel)
+
+
+def live_pmc_summary(args):
+    """rocprofv3 --pmc passes over `bench.py --pmc-child` with this run's workload, as child processes of a parent
+    that has not touched the GPU yet (tools/pmc.py).  Returns the summary dict or (None, reason)."""
+    import pmc
+    if args.gpus != 1 or "WORLD_SIZE" in os.environ:
+        return None, "PMC passes are single-GPU"
+    import shutil
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 is not on PATH"
+    child = ["--workload", args.workload] + (["--spp", str(args.spp)] if args.spp else [])
+    t0 = time.time()
+    summary = pmc.collect(child, log=lambda m: sys.stderr.write("bench.py: %s\n" % m))
+    summary["_stamp"]["collected_in_s"] = round(time.time() - t0, 1)
+    return summary, None
+
+
+def mean_of(c, name):
+    return c[name]["mean"] if name in c else None
 
 
 def valu_roofline(c, kernel_ms, segments):
-    """VALU-issue view of one launch.  SQ_ACTIVE_INST_VALU counts, per SIMD, cycles/4 with a vector
-    instruction executing (MI355X_MICROARCH.md, SQ counters): x4 = busy SIMD-cycles.  Peak = every SIMD
-    busy every cycle of the LIVE kernel duration at the peak clock.  (Four cycles are booked per instruction,
-    but plain 32-bit VOP2 instructions issue in 2.3 — tools/microbench/valu_cost.hip — so two waves' bookings
-    can overlap and the fraction can pass 1 by a few per cent at six waves per SIMD: it means "at the limit".)"""
-    busy_cycles = 4.0 * c["SQ_ACTIVE_INST_VALU"]["mean"]
+    """Vector-ALU view of one launch from the SQ counters (per-dispatch means) and the LIVE kernel duration.
+    frac       = f64 FLOP/s over the f64 vector peak: (ADD + MUL + TRANS + 2 FMA) f64 wave-instructions x the mean
+                 active lanes per vector instruction (the counters give no per-class lane count) / kernel time.
+    issue_frac = sum over classes of instructions x the class's MINIMUM issue cost (ISSUE_COST) over the SIMD-cycles
+                 of the launch at the peak clock: the share of the launch in which the vector pipes were provably
+                 occupied.  Both are <= 1 by construction.
+    valu_busy  = 4 x SQ_ACTIVE_INST_VALU / SIMD-cycles: the hardware's own busy figure; it books a quad-cycle per
+                 instruction although 32-bit ones issue in 2, so it can pass 1 (round 2 printed it as `frac`)."""
     secs = kernel_ms * 1e-3
-    achieved = busy_cycles / secs / 1e9
-    peak = SIMDS * CLOCK_GHZ
+    simd_cycles = SIMDS * CLOCK_GHZ * 1e9 * secs
+    total = c["SQ_INSTS_VALU"]["mean"]
     lanes = c["SQ_THREAD_CYCLES_VALU"]["mean"] / c["SQ_ACTIVE_INST_VALU"]["mean"]
-    return {"achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "G busy SIMD-cycles/s",
-            "frac": round(achieved / peak, 4),
-            "valu_insts_per_launch": c["SQ_INSTS_VALU"]["mean"],
-            "valu_insts_per_segment": round(c["SQ_INSTS_VALU"]["mean"] / segments, 3),
-            "lanes_per_inst": round(lanes, 1),
-            "useful_lane_frac": round(achieved / peak * lanes / 64.0, 4),
-            "kernel_ms_under_pmc": c["_stamp"].get("kernel_ms_under_pmc"),
-            "note": "the counter books 4 cycles per vector instruction; plain 32-bit VOP2 instructions issue in 2.3 "
-                    "(profiles/r02_valu_cost.txt), so with several waves per SIMD the sum can pass the SIMD-cycles "
-                    "available: a frac near or above 1 says the launch is at the VALU issue limit",
-            "source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU (own pass), %s, "
-                      "source stamp %s" % (c["_path"], c["_stamp"]["source_sha"][:12])}
+    out = {"valu_busy": round(4.0 * c["SQ_ACTIVE_INST_VALU"]["mean"] / simd_cycles, 4),
+           "lanes_per_inst": round(lanes, 1),
+           "valu_insts_per_launch": total,
+           "valu_insts_per_segment": round(total / segments, 3)}
+    if mean_of(c, "SQ_WAVE_CYCLES") and mean_of(c, "SQ_WAIT_INST_ANY") is not None:
+        out["wave_time_waiting_frac"] = round(c["SQ_WAIT_INST_ANY"]["mean"] / c["SQ_WAVE_CYCLES"]["mean"], 4)
+        if mean_of(c, "SQ_ACTIVE_INST_ANY") is not None:
+            out["wave_time_issuing_frac"] = round(c["SQ_ACTIVE_INST_ANY"]["mean"] / c["SQ_WAVE_CYCLES"]["mean"], 4)
+    f64 = [mean_of(c, "SQ_INSTS_VALU_%s_F64" % k) for k in ("ADD", "MUL", "FMA", "TRANS")]
+    if None in f64:
+        out["frac"] = out["achieved"] = None
+        out["per_class_counters"] = "missing: %s" % "; ".join(c["_stamp"].get("errors", []))
+        return out
+    add, mul, fma, trans = f64
+    flops = (add + mul + trans + 2.0 * fma) * lanes
+    achieved = flops / secs / 1e12
+    classes = {"f64": add + mul + fma, "trans_f64": trans}
+    f32 = [mean_of(c, "SQ_INSTS_VALU_%s_F32" % k) or 0.0 for k in ("ADD", "MUL", "FMA")]
+    classes["f32"] = sum(f32)
+    classes["trans_f32"] = mean_of(c, "SQ_INSTS_VALU_TRANS_F32") or 0.0
+    classes["int32"] = mean_of(c, "SQ_INSTS_VALU_INT32") or 0.0
+    classes["int64"] = mean_of(c, "SQ_INSTS_VALU_INT64") or 0.0
+    classes["cvt"] = mean_of(c, "SQ_INSTS_VALU_CVT") or 0.0
+    classes["other"] = max(0.0, total - sum(classes.values()))  # moves, selects, compares, lane ops
+    issue_cycles = sum(n * ISSUE_COST[k] for k, n in classes.items())
+    out.update({"achieved": round(achieved, 3), "peak": F64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / F64_VECTOR_PEAK_TFLOPS, 4),
+                "issue_frac": round(issue_cycles / simd_cycles, 4),
+                "f64_flop_per_segment": round(flops / segments, 2),
+                "valu_insts_by_class": {k: round(v / total, 4) for k, v in classes.items()},
+                "issue_cost_cycles": ISSUE_COST})
+    return out
 
 
 def hbm_traffic(c):
@@ -177,6 +255,44 @@ def hbm_traffic(c):
     if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
         return None
     return 2.0 * c["FETCH_SIZE"]["mean"] * 1024.0 + c["WRITE_SIZE"]["mean"] * 1024.0
+
+
+def host_delivery(rt, scene, session, reps=5):
+    """What a binding of the reference receives: the wall time of rt_render (cpu.rs:73-115's tile grid, every tile
+    copied out of the callback into a host frame, as `rgb.to_vec()` would) and of rt_render_frame into a caller-owned
+    frame.  Pinned staging is the library's business; the destination here is ordinary pageable memory."""
+    import ctypes as C
+    import numpy as np
+    abi = rt.abi
+    p = abi.RtRenderParams.from_buffer_copy(session.params)
+    p.strip_count = 0
+    W, H = p.width, p.height
+    frame = np.zeros((H, W, 3), dtype=np.float64)
+    tiles = []
+
+    def on_tile(_user, rgb, r, c, w, h):
+        frame[r:r + h, c:c + w] = np.ctypeslib.as_array(rgb, shape=(h, w, 3))
+        tiles.append(1)
+
+    cb = abi.RtTileCallback(on_tile)
+    lib = rt.lib()
+    out = {}
+    for name, call in (("rt_render", lambda: lib.rt_render(scene._h, C.byref(session.camera), C.byref(p), cb, None, None)),
+                       ("rt_render_frame", lambda: lib.rt_render_frame(scene._h, C.byref(session.camera), C.byref(p),
+                                                                     frame.ctypes.data_as(C.POINTER(C.c_double))))):
+        rt.check(call(), name)  # warm-up (pinned frame, counters)
+        times = []
+        for _ in range(reps):
+            del tiles[:]
+            t0 = time.perf_counter()
+            rt.check(call(), name)
+            times.append(time.perf_counter() - t0)
+        ms = sum(times) / len(times) * 1e3
+        out[name] = {"ms": round(ms, 3), "value": round(W * H * p.samples / (ms * 1e-3) / 1e6, 2), "unit": "Msamples/s",
+                     "calls": reps}
+        if name == "rt_render":
+            out[name]["tiles"] = "%dx%d grid, %d callbacks per call" % (p.tiles_w, p.tiles_h, len(tiles))
+    return out
 
 
 def free_port():
@@ -216,6 +332,10 @@ def main():
     args = parse()
     if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))  # before torch / HIP are even imported
+    # LIVE counters: rocprofv3 passes over this command, as children, before this process touches the GPU
+    live_summary, live_why_not = (None, "--pmc %s" % args.pmc)
+    if args.pmc == "live":
+        live_summary, live_why_not = live_pmc_summary(args)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -254,12 +374,16 @@ def main():
     # when a collective runs the frame lives in the gather's staging buffer: no copies besides the strips
     frame = gatherer.frame() if gatherer.collective else torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream()
+    rgba = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") if rank == 0 else None
     kernel_ms, segments = [], []
 
     def step(record):
-        # trace + resolve on torch's current stream, then the one collective of the path
+        # trace + resolve on torch's current stream, then the one collective of the path, then (on the rank that
+        # holds the whole frame) ScreenBuffer::update's tone map + SavePng's RGBA8 packing in one pass
         scene.render_frame_device(session.camera, p, frame.data_ptr(), stream.cuda_stream)
         gatherer.gather(frame)
+        if rank == 0:
+            scene.post_rgba8_device(session.tone_map_desc, frame.data_ptr(), W * H, rgba.data_ptr(), None, stream.cuda_stream)
         if record:
             st = scene.last_stats()  # HIP events on the launch stream
             kernel_ms.append(st.kernel_ms)
@@ -302,7 +426,16 @@ def main():
         seg_per_step = total_segments / recorded
         k_ms = kernel_total_ms / recorded
         algorithmic = BYTES_PER_SEGMENT_F64 * seg_per_step / (k_ms * 1e-3) / 1e9 / world  # GB/s per GPU
-        counters, why_not = pmc_summary(args.workload, workload, world)
+        counters, why_not, origin = None, live_why_not, None
+        if live_summary is not None:
+            counters, why_not = trace_kernel_counters(live_summary, workload, "live rocprofv3 passes of this run")
+            origin = "live"
+        if counters is None and args.pmc != "none" and world == 1:
+            why_live = why_not
+            counters, why_not = committed_pmc_summary(args.workload, workload)
+            origin = "file"
+            if counters is None:
+                why_not = "live: %s; file: %s" % (why_live, why_not)
         out = {
             "metric": "Msamples/s (W*H*spp/s) at %dx%d" % (W, H),
             "value": round(value, 2),
@@ -321,9 +454,11 @@ def main():
                                       % (world, "" if dist is None else
                                          (", gloo gather to rank 0 (one-card rehearsal, NOT RCCL)" if rehearsal
                                           else ", RCCL gather to rank 0"))},
+            "step": "rt_render_frame_device (trace + resolve)%s + rt_post_rgba8_device (tone map %s + RGBA8)"
+                    % (" + gather" if dist is not None else "", session.tone_map_name),
             "roofline": {
                 "bound": "valu",
-                "achieved": None, "peak": round(SIMDS * CLOCK_GHZ, 1), "unit": "G busy SIMD-cycles/s", "frac": None,
+                "achieved": None, "peak": F64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
                 "traffic": None,
                 "kernel": "k_trace_pool_f64",
                 "kernel_ms": round(k_ms, 3),
@@ -342,6 +477,12 @@ def main():
         }
         if counters is not None:
             out["roofline"].update(valu_roofline(counters, k_ms, seg_per_step))
+            out["roofline"]["counters"] = {
+                "origin": origin, "source": counters["_origin"], "kernel": counters["_kernel"],
+                "source_stamp": counters["_stamp"]["source_sha"][:12],
+                "kernel_ms_under_pmc": counters["_stamp"].get("kernel_ms_under_pmc"),
+                "collected_in_s": counters["_stamp"].get("collected_in_s"),
+                "how": "rocprofv3 --pmc, one pass per counter group (tools/pmc.py), per-dispatch means"}
             traffic = hbm_traffic(counters)
             if traffic is not None:
                 # measured HBM bytes per launch over the live kernel duration
@@ -350,6 +491,10 @@ def main():
                 out["roofline"]["traffic_frac_of_hbm_peak"] = round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         else:
             out["roofline"]["counters_unavailable"] = why_not
+        if world == 1 and dist is None and not args.no_host_delivery:
+            out["host_delivered"] = host_delivery(rt, scene, session)
+            out["host_delivered"]["vs_device_resident"] = {
+                k: round(out["host_delivered"][k]["ms"] / ms_per_step, 4) for k in ("rt_render", "rt_render_frame")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(session, args.cpu_seconds)
         if rehearsal:

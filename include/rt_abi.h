@@ -263,10 +263,24 @@ enum RtTraceKernel {
     RT_KERNEL_POOL = 0, /* k_trace_pool_f64: persistent waves over a pool of paths (default) */
     RT_KERNEL_V1 = 1    /* k_trace_f64: lane = pixel; the simple second implementation */
 };
+/* Arithmetic of the trace kernels.  The reference divides (vec3.rs:79-85 unit_vector, sphere.rs:52,
+ * xy_rect.rs:31) and multiplies by 1/x (vec3.rs:279-301) in IEEE f64 without FMA contraction.
+ *   RT_ARITH_FAST (default): one reciprocal / reciprocal square root per ray from the hardware seed, refined to
+ *     <= 1 ulp, FMA contraction on.  Against the reference's arithmetic (the oracle) the shipped scenes agree to
+ *     ~1e-13 per channel; a scene that amplifies rounding (thousands of small mirrors: a bounce multiplies a
+ *     direction error by distance / radius) can flip the odd hit, i.e. a few pixels in ten thousand beyond 1e-3.
+ *   RT_ARITH_REFERENCE: the reference's own operations (IEEE divisions, sqrt + three divisions, no contraction);
+ *     holds the 1e-3 per-channel tolerance on such scenes too; ~25 % slower.  Same kernels, same draws, same
+ *     closest-hit rule: only the last bits of the arithmetic differ. */
+enum RtArithmetic {
+    RT_ARITH_FAST = 0,
+    RT_ARITH_REFERENCE = 1
+};
 typedef struct RtSceneOptions {
     int32_t closest_hit; /* RtClosestHit  */
     int32_t kernel;      /* RtTraceKernel */
-    int32_t _reserved[6]; /* must be 0 */
+    int32_t arithmetic;  /* RtArithmetic  */
+    int32_t _reserved[5]; /* must be 0 */
 } RtSceneOptions;
 
 /* Statistics of the last render on a scene (path segments = ray_color

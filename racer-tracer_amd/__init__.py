@@ -116,14 +116,16 @@ def render_tiles_multi(scenes, camera, params, strip_rows=0, cancel=None):
 class Scene:
     """RtScene handle: a scene uploaded to one GPU (rt_scene_create)."""
 
-    def __init__(self, desc, device=0, closest_hit=abi.RT_HIT_AUTO, kernel=abi.RT_KERNEL_POOL, library=None):
-        """closest_hit / kernel: RtSceneOptions (rt_scene_create_ex) — implementation choices
-        the parity tests pin; the defaults are rt_scene_create's own.  library: load_library()."""
+    def __init__(self, desc, device=0, closest_hit=abi.RT_HIT_AUTO, kernel=abi.RT_KERNEL_POOL, library=None,
+                 arithmetic=abi.RT_ARITH_FAST):
+        """closest_hit / kernel / arithmetic: RtSceneOptions (rt_scene_create_ex) — the defaults are
+        rt_scene_create's own; arithmetic=RT_ARITH_REFERENCE selects the reference's IEEE divisions without FMA
+        contraction.  library: load_library()."""
         self._lib = library or lib()
         self._h = C.c_void_p()
         self._desc_owner = desc  # keep SceneBundle / host session alive
         d = desc.desc if hasattr(desc, "desc") else desc
-        opt = abi.RtSceneOptions(closest_hit, kernel)
+        opt = abi.RtSceneOptions(closest_hit, kernel, arithmetic)
         check(self._lib.rt_scene_create_ex(C.byref(d), device, C.byref(opt), C.byref(self._h)), "rt_scene_create_ex", self._lib)
         self.device = device
 

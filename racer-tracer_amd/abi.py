@@ -103,10 +103,11 @@ class RtToneMap(C.Structure):
 
 RT_HIT_AUTO, RT_HIT_LINEAR, RT_HIT_BVH = 0, 1, 2
 RT_KERNEL_POOL, RT_KERNEL_V1 = 0, 1
+RT_ARITH_FAST, RT_ARITH_REFERENCE = 0, 1
 
 
 class RtSceneOptions(C.Structure):
-    _fields_ = [("closest_hit", C.c_int32), ("kernel", C.c_int32), ("_reserved", C.c_int32 * 6)]
+    _fields_ = [("closest_hit", C.c_int32), ("kernel", C.c_int32), ("arithmetic", C.c_int32), ("_reserved", C.c_int32 * 5)]
 
 
 RtTileCallback = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_int32,

@@ -15,20 +15,25 @@
 #include "rt_bvh.h"
 #include "rt_scene.h"
 
-extern "C" hipError_t rtdev_launch_trace(const rtdev::TraceArgs *args, int prims_class, int textured,
-                                         int specular, hipStream_t stream);
-extern "C" hipError_t rtdev_launch_resolve(const double *accum, double *out, int width, int height,
-                                           int strip_rows, int strip_count, int strip_index, int samples,
-                                           hipStream_t stream);
+// The trace kernels exist twice (rt_trace_common.h: ARITHMETIC): RT_ARITH_FAST, and RT_ARITH_REFERENCE behind *_exact.
+#define RT_DECLARE_LAUNCHERS(SUFFIX)                                                                                       \
+    extern "C" hipError_t rtdev_launch_trace##SUFFIX(const rtdev::TraceArgs *args, int prims_class, int textured,         \
+                                                     int specular, hipStream_t stream);                                   \
+    extern "C" hipError_t rtdev_launch_resolve##SUFFIX(const double *accum, double *out, int width, int height,           \
+                                                       int strip_rows, int strip_count, int strip_index, int samples,     \
+                                                       hipStream_t stream);                                               \
+    extern "C" int rtdev_pool_blocks_per_cu##SUFFIX(int prims_class, int textured, int specular, int bvh, size_t dyn_lds); \
+    extern "C" hipError_t rtdev_launch_trace_pool##SUFFIX(const rtdev::TraceArgs *args, int prims_class, int textured,    \
+                                                          int specular, int bvh, unsigned blocks, hipStream_t stream);    \
+    extern "C" hipError_t rtdev_launch_resolve_chunks##SUFFIX(const double *partial, double *out, int width, int height,  \
+                                                              int n_chunks, int strip_rows, int strip_count,              \
+                                                              int strip_index, int step_x, int step_y, int cover_w,       \
+                                                              int cover_h, int x0, int x_count, int samples,              \
+                                                              hipStream_t stream);
+RT_DECLARE_LAUNCHERS()
+RT_DECLARE_LAUNCHERS(_exact)
 extern "C" hipError_t rtdev_launch_post_rgba8(const RtToneMap *tm, const double *rgb, size_t n_pixels, uint8_t *rgba,
                                               double *mapped, hipStream_t stream);
-extern "C" int rtdev_pool_blocks_per_cu(int prims_class, int textured, int specular, int bvh, size_t dyn_lds);
-extern "C" hipError_t rtdev_launch_trace_pool(const rtdev::TraceArgs *args, int prims_class, int textured, int specular,
-                                              int bvh, unsigned blocks, hipStream_t stream);
-extern "C" hipError_t rtdev_launch_resolve_chunks(const double *partial, double *out, int width, int height, int n_chunks,
-                                                  int strip_rows, int strip_count, int strip_index, int step_x, int step_y,
-                                                  int cover_w, int cover_h, int x0, int x_count, int samples,
-                                                  hipStream_t stream);
 
 thread_local std::string g_last_error;
 
@@ -290,12 +295,12 @@ int rtapi::enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderPara
             if (cancel.raised()) return RT_ERR_CANCEL_EVENT;
             a.sample_begin = b;
             a.sample_end = b + batch < p->samples ? b + batch : p->samples;
-            RT_HIP(rtdev_launch_trace(&a, s->prims_class, s->textured, s->specular, stream));
+            RT_HIP((s->exact ? rtdev_launch_trace_exact : rtdev_launch_trace)(&a, s->prims_class, s->textured, s->specular, stream));
             ++launches;
             if (cancel.armed()) RT_HIP(hipStreamSynchronize(stream)); // so the next poll is meaningful
         }
         RT_HIP(hipEventRecord(s->ev_traced, stream));
-        RT_HIP(rtdev_launch_resolve(s->accum.ptr, out_device, p->width, p->height, a.strip_rows, a.strip_count,
+        RT_HIP((s->exact ? rtdev_launch_resolve_exact : rtdev_launch_resolve)(s->accum.ptr, out_device, p->width, p->height, a.strip_rows, a.strip_count,
                                     a.strip_index, p->samples, stream));
         RT_HIP(hipEventRecord(s->ev_resolved, stream));
     } else {
@@ -384,13 +389,13 @@ int rtapi::enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderPara
             unsigned blocks = (unsigned)(s->num_cus * (a.lens_lds ? s->pool_blocks_per_cu_lens : s->pool_blocks_per_cu));
             unsigned needed = (a.n_items + 3) / 4;
             if (blocks > needed) blocks = needed;
-            RT_HIP(rtdev_launch_trace_pool(&a, s->prims_class, s->textured, s->specular, s->use_bvh, blocks, stream));
+            RT_HIP((s->exact ? rtdev_launch_trace_pool_exact : rtdev_launch_trace_pool)(&a, s->prims_class, s->textured, s->specular, s->use_bvh, blocks, stream));
             chunks_done += a.n_chunks;
             ++launches;
         }
         RT_HIP(hipEventRecord(s->ev_traced, stream));
         if (!delivery)
-            RT_HIP(rtdev_launch_resolve_chunks(s->partial.ptr, out_device, p->width, p->height, chunks_done, a.strip_rows,
+            RT_HIP((s->exact ? rtdev_launch_resolve_chunks_exact : rtdev_launch_resolve_chunks)(s->partial.ptr, out_device, p->width, p->height, chunks_done, a.strip_rows,
                                                a.strip_count, a.strip_index, a.step_x, a.step_y, a.cover_w, a.cover_h, 0,
                                                p->width, p->samples, stream));
         RT_HIP(hipEventRecord(s->ev_resolved, stream));
@@ -529,6 +534,7 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
     if (options) opt = *options;
     if (opt.closest_hit < RT_HIT_AUTO || opt.closest_hit > RT_HIT_BVH) return fail(RT_ERR_INVALID_ARGUMENT, "unknown closest_hit option");
     if (opt.kernel < RT_KERNEL_POOL || opt.kernel > RT_KERNEL_V1) return fail(RT_ERR_INVALID_ARGUMENT, "unknown kernel option");
+    if (opt.arithmetic < RT_ARITH_FAST || opt.arithmetic > RT_ARITH_REFERENCE) return fail(RT_ERR_INVALID_ARGUMENT, "unknown arithmetic option");
     for (int32_t r : opt._reserved)
         if (r != 0) return fail(RT_ERR_INVALID_ARGUMENT, "reserved option fields must be 0");
     int n_dev = rt_device_count();
@@ -539,6 +545,7 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
     RtScene *s = new (std::nothrow) RtScene();
     if (!s) return fail(RT_ERR_OUT_OF_MEMORY, "host allocation failed");
     s->device = device;
+    s->exact = opt.arithmetic == RT_ARITH_REFERENCE;
     struct Guard { // destroy the half-built scene on any early return
         RtScene *s;
         ~Guard() { if (s) rt_scene_destroy(s); }
@@ -671,7 +678,7 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
         const size_t lds_other = s->textured && d->n_perlins > 0 && s->perlin_identity ? sizeof(double) * 256 * 3 : 0;
         auto blocks_with = [&](const rtdev::BvhBuild &b) {
             const size_t bytes = b.nodes.size() * sizeof(rtdev::BvhNode);
-            return rtdev_pool_blocks_per_cu(s->prims_class, s->textured, s->specular, 1, (bytes <= 32 * 1024 ? bytes : 0) + lds_other);
+            return (s->exact ? rtdev_pool_blocks_per_cu_exact : rtdev_pool_blocks_per_cu)(s->prims_class, s->textured, s->specular, 1, (bytes <= 32 * 1024 ? bytes : 0) + lds_other);
         };
         rtdev::BvhBuild bvh = rtdev::build_bvh(d->primitives, d->n_primitives, 4);
         int max_leaf = 0;
@@ -744,8 +751,8 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
     const size_t dyn_lds = (s->use_bvh ? (s->bvh_nodes_in_lds ? (size_t)s->n_bvh_nodes * sizeof(rtdev::BvhNode) : 0)
                                        : (size_t)s->n_prims * sizeof(rtdev::Prim) + (s->textured ? (size_t)s->n_textures * sizeof(rtdev::Texture) : 0)) +
                            (s->textured && s->n_perlins > 0 && s->perlin_identity ? sizeof(double) * 256 * 3 : 0);
-    s->pool_blocks_per_cu = rtdev_pool_blocks_per_cu(s->prims_class, s->textured, s->specular, s->use_bvh, dyn_lds);
-    s->pool_blocks_per_cu_lens = rtdev_pool_blocks_per_cu(s->prims_class, s->textured, s->specular, s->use_bvh,
+    s->pool_blocks_per_cu = (s->exact ? rtdev_pool_blocks_per_cu_exact : rtdev_pool_blocks_per_cu)(s->prims_class, s->textured, s->specular, s->use_bvh, dyn_lds);
+    s->pool_blocks_per_cu_lens = (s->exact ? rtdev_pool_blocks_per_cu_exact : rtdev_pool_blocks_per_cu)(s->prims_class, s->textured, s->specular, s->use_bvh,
                                                           dyn_lds + rtdev::pool_lens_lds_bytes(s->use_bvh != 0));
 #ifdef RT_DEVELOPER_KNOBS // occupancy experiments
     if (const char *k = getenv("RT_POOL_BLOCKS_PER_CU"))

@@ -9,9 +9,28 @@
 #include "../../include/rt_abi.h"
 #include "../../include/rt_rng.h"
 
-namespace rtdev {
+// ARITHMETIC.  The trace kernels exist twice in the library (RtSceneOptions.arithmetic):
+//   RT_ARITH_FAST      — reciprocals and reciprocal square roots once per ray from the hardware seeds (<= 1 ulp), FMA
+//                        contraction on: the default;
+//   RT_ARITH_REFERENCE — the reference's own operations: IEEE divisions (vec3.rs:279-301 multiplies by 1/x,
+//                        sphere.rs:52 and xy_rect.rs:31 divide), sqrt + three divisions for unit_vector
+//                        (vec3.rs:79-85), no FMA contraction.  Compiled from the SAME sources with -DRT_EXACT_DIV
+//                        -ffp-contract=off into namespace rtdev_exact and launchers named *_exact.
+// Everything that is not arithmetic (types, tables, TraceArgs) is shared: namespace rtdev.
+#ifdef RT_EXACT_DIV
+#define RT_KNS rtdev_exact
+#define RT_LAUNCHER(name) name##_exact
+#else
+#define RT_KNS rtdev_fast
+#define RT_LAUNCHER(name) name
+#endif
 
+namespace rtdev {
 enum { PRIMS_RECTS = 0, PRIMS_SPHERES = 1, PRIMS_ANY = 2 };
+}
+
+namespace RT_KNS {
+using namespace rtdev;
 
 // Scene tables are never written while a trace kernel runs.  Reading them
 // through the constant address space lets the backend use scalar loads (s_load,
@@ -60,10 +79,11 @@ __device__ __forceinline__ d3 unit(d3 a) {
 // refinement the compiler's full f64 division uses, without its scaling and
 // fix-up instructions).  Used where the reference divides several values by
 // one denominator; results differ from true division by an ulp or two.
-// -DRT_EXACT_DIV (tests only, build/libracer_tracer_amd_exact.so, compiled -ffp-contract=off): the
+// -DRT_EXACT_DIV (the RT_ARITH_REFERENCE copy of the kernels, compiled -ffp-contract=off): the
 // reference's own operations instead — IEEE division (vec3.rs:279-301 multiplies by 1/x, sphere.rs:52
 // and xy_rect.rs:31 divide) and sqrt + three divisions for unit_vector (vec3.rs:79-85) — so that a
-// parity test can tell an arithmetic difference from a traversal defect.
+// caller can have the reference's arithmetic, and a parity test can tell an arithmetic difference from a
+// traversal defect.
 __device__ __forceinline__ double rcp_f64(double x) {
 #ifdef RT_EXACT_DIV
     return 1.0 / x;
@@ -683,4 +703,4 @@ __device__ __forceinline__ d3 texture_value(const TraceArgs &A, const Perlin *ld
     return texture_value_full(A, lds_perlin, textures, M.texture, u, v, p);
 }
 
-} // namespace rtdev
+} // namespace RT_KNS

@@ -6,7 +6,7 @@
 // the default.  Selected with RtSceneOptions.kernel = RT_KERNEL_V1 (rt_scene_create_ex).
 #include "rt_trace_common.h"
 
-namespace rtdev {
+namespace RT_KNS {
 
 // ------------------------------------------------------------- the kernel
 // 256 threads = 4 waves; each wave owns an 8x8 pixel tile, each block a
@@ -214,12 +214,12 @@ __global__ __launch_bounds__(256) void k_resolve_f64(const double *__restrict__ 
     }
 }
 
-} // namespace rtdev
+} // namespace RT_KNS
 
 namespace {
 template <int PRIMS, bool TEXTURED, bool SPECULAR>
 void launch_variant(const rtdev::TraceArgs &a, unsigned blocks, hipStream_t stream) {
-    hipLaunchKernelGGL((rtdev::k_trace_f64<PRIMS, TEXTURED, SPECULAR>), dim3(blocks), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((RT_KNS::k_trace_f64<PRIMS, TEXTURED, SPECULAR>), dim3(blocks), dim3(256), 0, stream, a);
 }
 template <int PRIMS>
 void launch_prims(const rtdev::TraceArgs &a, bool textured, bool specular, unsigned blocks, hipStream_t stream) {
@@ -234,7 +234,7 @@ void launch_prims(const rtdev::TraceArgs &a, bool textured, bool specular, unsig
 } // namespace
 
 // prims_class: rtdev::PRIMS_*; textured/specular: scene feature flags (see k_trace_f64)
-extern "C" hipError_t rtdev_launch_trace(const rtdev::TraceArgs *args, int prims_class, int textured,
+extern "C" hipError_t RT_LAUNCHER(rtdev_launch_trace)(const rtdev::TraceArgs *args, int prims_class, int textured,
                                          int specular, hipStream_t stream) {
     int tiles_x = (args->width + 15) / 16;
     int tiles_y = (args->owned_rows + 15) / 16;
@@ -248,14 +248,14 @@ extern "C" hipError_t rtdev_launch_trace(const rtdev::TraceArgs *args, int prims
     return hipGetLastError();
 }
 
-extern "C" hipError_t rtdev_launch_resolve(const double *accum, double *out, int width, int height,
+extern "C" hipError_t RT_LAUNCHER(rtdev_launch_resolve)(const double *accum, double *out, int width, int height,
                                            int strip_rows, int strip_count, int strip_index, int samples,
                                            hipStream_t stream) {
     size_t n = (size_t)width * (size_t)height * 3;
     unsigned blocks = (unsigned)((n + 255) / 256);
     if (blocks > 2048u) blocks = 2048u;
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(rtdev::k_resolve_f64, dim3(blocks), dim3(256), 0, stream, accum, out, width, height,
+    hipLaunchKernelGGL(RT_KNS::k_resolve_f64, dim3(blocks), dim3(256), 0, stream, accum, out, width, height,
                        strip_rows, strip_count, strip_index, 1.0 / (double)samples);
     return hipGetLastError();
 }

@@ -81,7 +81,7 @@
 #define RT_OCC_PLAIN 6 // rects-only / spheres-only, no textures, no specular materials: 80 VGPRs, six blocks per CU when LDS allows (the bound is what keeps
                        // the allocator there: with 5 it drifts to 81-89 whenever the code around the path loop changes, and the sixth block is worth 4 %)
 #endif
-namespace rtdev {
+namespace RT_KNS {
 
 // -DRT_PROFILE_REGIONS: developer build that accumulates the shader-clock cycles each wave
 // spends per region of the path loop into A.segments[RT_STAT_REGIONS..]; rt_scene_last_stats prints them
@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(256) void k_resolve_chunks_f64(const double *__rest
     }
 }
 
-} // namespace rtdev
+} // namespace RT_KNS
 
 namespace {
 // One table entry per compiled variant: PRIMS x TEXTURED x SPECULAR with the
@@ -1013,11 +1013,11 @@ template <int PRIMS, bool TEXTURED, bool SPECULAR, bool BVH> struct PoolVariant 
                                 : (size_t)a.n_prims * sizeof(rtdev::Prim) + (TEXTURED ? (size_t)a.n_textures * sizeof(rtdev::Texture) : 0)) +
                            (TEXTURED && a.perlin_in_lds ? sizeof(double) * 256 * 3 : 0) +
                            (a.lens_lds ? rtdev::pool_lens_lds_bytes(BVH) : 0);
-        hipLaunchKernelGGL((rtdev::k_trace_pool_f64<PRIMS, TEXTURED, SPECULAR, BVH>), dim3(blocks), dim3(256), dyn, stream, a);
+        hipLaunchKernelGGL((RT_KNS::k_trace_pool_f64<PRIMS, TEXTURED, SPECULAR, BVH>), dim3(blocks), dim3(256), dyn, stream, a);
     }
     static int blocks_per_cu(size_t dyn_lds) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rtdev::k_trace_pool_f64<PRIMS, TEXTURED, SPECULAR, BVH>, 256, dyn_lds) != hipSuccess)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, RT_KNS::k_trace_pool_f64<PRIMS, TEXTURED, SPECULAR, BVH>, 256, dyn_lds) != hipSuccess)
             return 1;
         return n < 1 ? 1 : n;
     }
@@ -1038,12 +1038,12 @@ template <class F> auto dispatch_variant(int prims_class, bool textured, bool sp
 } // namespace
 
 // Resident blocks per CU of the variant (the persistent grid is CUs x this).
-extern "C" int rtdev_pool_blocks_per_cu(int prims_class, int textured, int specular, int bvh, size_t dyn_lds) {
+extern "C" int RT_LAUNCHER(rtdev_pool_blocks_per_cu)(int prims_class, int textured, int specular, int bvh, size_t dyn_lds) {
     return dispatch_variant(prims_class, textured != 0, specular != 0, bvh != 0,
                             [dyn_lds](auto v) { return decltype(v)::blocks_per_cu(dyn_lds); });
 }
 
-extern "C" hipError_t rtdev_launch_trace_pool(const rtdev::TraceArgs *args, int prims_class, int textured, int specular,
+extern "C" hipError_t RT_LAUNCHER(rtdev_launch_trace_pool)(const rtdev::TraceArgs *args, int prims_class, int textured, int specular,
                                               int bvh, unsigned blocks, hipStream_t stream) {
     if (blocks == 0 || args->n_items == 0) return hipSuccess;
     dispatch_variant(prims_class, textured != 0, specular != 0, bvh != 0, [&](auto v) {
@@ -1053,7 +1053,7 @@ extern "C" hipError_t rtdev_launch_trace_pool(const rtdev::TraceArgs *args, int 
     return hipGetLastError();
 }
 
-extern "C" hipError_t rtdev_launch_resolve_chunks(const double *partial, double *out, int width, int height, int n_chunks,
+extern "C" hipError_t RT_LAUNCHER(rtdev_launch_resolve_chunks)(const double *partial, double *out, int width, int height, int n_chunks,
                                                   int strip_rows, int strip_count, int strip_index, int step_x, int step_y,
                                                   int cover_w, int cover_h, int x0, int x_count, int samples,
                                                   hipStream_t stream) {
@@ -1065,7 +1065,7 @@ extern "C" hipError_t rtdev_launch_resolve_chunks(const double *partial, double 
     unsigned blocks = (unsigned)((n + 255) / 256);
     if (blocks > 4096u) blocks = 4096u;
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(rtdev::k_resolve_chunks_f64, dim3(blocks), dim3(256), 0, stream, partial, out, width, height,
+    hipLaunchKernelGGL(RT_KNS::k_resolve_chunks_f64, dim3(blocks), dim3(256), 0, stream, partial, out, width, height,
                        n_chunks, strip_rows, strip_count, strip_index, step_x, step_y, cover_w, cover_h, x0, x_count,
                        1.0 / (double)samples);
     return hipGetLastError();

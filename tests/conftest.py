@@ -48,6 +48,7 @@ def gpu(rt):
 # any test runs, and tests/test_bench_launch.py only collects its result.
 def pytest_sessionstart(session):
     session.config._bench_rehearsal = None
+    session.config._bench_force_dist = None
     session.config._cli_run = None
     if (session.config.getoption("-m") or "").strip() != "gpu":
         return
@@ -61,6 +62,16 @@ def pytest_sessionstart(session):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--spp", "64", "--no-cpu-baseline"]
     session.config._bench_rehearsal = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=log, env=env, text=True, cwd=ROOT)
+    # ... and RCCL for real: `bench.py --force-dist` = torch.distributed.run with ONE rank, init_process_group("nccl"),
+    # the strip gather forced through dist.gather on the f64 device tensors, an all_reduce of the timings.  What a
+    # multi-GPU node would otherwise be the first to find out: librccl loads, device_id= is accepted, f64 gathers work.
+    log2 = open(os.path.join(out_dir, "bench_force_dist.stderr.log"), "w")
+    env2 = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BENCH_REHEARSE_ON_ONE_GPU"):
+        env2.pop(k, None)
+    cmd2 = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "2", "--warmup", "1",
+            "--spp", "64", "--no-cpu-baseline", "--pmc", "none"]
+    session.config._bench_force_dist = subprocess.Popen(cmd2, stdout=subprocess.PIPE, stderr=log2, env=env2, text=True, cwd=ROOT)
     # ... and the headless CLI end to end (-c/-s/--image-action png, the reference's flags), for the same reason
     import tempfile
     out = tempfile.mkdtemp(prefix="rt_cli_")
@@ -72,7 +83,8 @@ def pytest_sessionstart(session):
 
 
 def pytest_sessionfinish(session, exitstatus):
-    proc = getattr(session.config, "_bench_rehearsal", None)
-    if proc is not None and proc.poll() is None:  # the collecting test did not run (e.g. -x stopped earlier)
-        proc.kill()
-        proc.wait()
+    for name in ("_bench_rehearsal", "_bench_force_dist"):
+        proc = getattr(session.config, name, None)
+        if proc is not None and proc.poll() is None:  # the collecting test did not run (e.g. -x stopped earlier)
+            proc.kill()
+            proc.wait()

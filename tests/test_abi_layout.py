@@ -35,7 +35,7 @@ def test_python_prototypes_cover_the_headers(rt):
 
 
 def test_abi_version_and_strerror(rt):
-    assert rt.lib().rt_abi_version() == rt.abi.ABI_VERSION == 3
+    assert rt.lib().rt_abi_version() == rt.abi.ABI_VERSION == 4
     # error.rs:71-97 numbering
     for code, text in ((0, "Ok"), (4, "Unknown Material"), (7, "Cancel event"), (9, "Scene failed to load"),
                        (21, "Failed to open image"), (100, "No usable HIP device")):
@@ -93,6 +93,15 @@ def test_product_library_reads_no_environment_knob():
         assert "getenv" not in outside, f
 
 
+def test_both_arithmetics_are_in_the_one_library(rt):
+    """RT_ARITH_REFERENCE is an option of the shipped library (RtSceneOptions.arithmetic), not a second build: the
+    trace kernels are in it twice, and their launchers under both names."""
+    so = os.path.join(ROOT, "racer-tracer_amd", "lib", "libracer_tracer_amd.so")
+    symbols = subprocess.check_output(["nm", "-D", "--defined-only", so]).decode()
+    for name in ("rtdev_launch_trace_pool", "rtdev_launch_trace_pool_exact", "rtdev_pool_blocks_per_cu_exact"):
+        assert re.search(r"\b%s\b" % name, symbols), name
+
+
 def test_multi_device_entry_points_validate_before_touching_a_device(rt, abi):
     """rt_render_frame_multi* (cpu.rs:118-131 over GPUs): argument errors are reported without a device."""
     cam, p = abi.RtCamera(), abi.render_params(16, 16, 1)
@@ -101,6 +110,10 @@ def test_multi_device_entry_points_validate_before_touching_a_device(rt, abi):
     handles = (C.c_void_p * 2)(None, None)
     assert rt.lib().rt_render_frame_multi(handles, 2, C.byref(cam), C.byref(p), 0, out) == abi.RT_ERR_INVALID_ARGUMENT
     assert b"NULL" in rt.lib().rt_last_error_message()
+    noop = abi.RtTileCallback(lambda *a: None)
+    never = C.cast(None, abi.RtCancelCallback)
+    assert rt.lib().rt_render_multi(handles, 2, C.byref(cam), C.byref(p), 0, noop, None, never, None) == abi.RT_ERR_INVALID_ARGUMENT
+    assert rt.lib().rt_render_ex(None, C.byref(cam), C.byref(p), noop, None, never, None) == abi.RT_ERR_INVALID_ARGUMENT
 
 
 def test_scene_options_are_validated(rt, abi):
@@ -111,6 +124,8 @@ def test_scene_options_are_validated(rt, abi):
     assert rt.lib().rt_scene_create_ex(C.byref(bundle.desc), 0, C.byref(bad), C.byref(h)) == abi.RT_ERR_INVALID_ARGUMENT
     bad = abi.RtSceneOptions(0, 0)
     bad._reserved[2] = 1
+    assert rt.lib().rt_scene_create_ex(C.byref(bundle.desc), 0, C.byref(bad), C.byref(h)) == abi.RT_ERR_INVALID_ARGUMENT
+    bad = abi.RtSceneOptions(0, 0, 2)   # RtArithmetic: FAST = 0, REFERENCE = 1
     assert rt.lib().rt_scene_create_ex(C.byref(bundle.desc), 0, C.byref(bad), C.byref(h)) == abi.RT_ERR_INVALID_ARGUMENT
 
 

@@ -43,7 +43,32 @@ def test_bench_self_launches_two_ranks(request, gpu):
         json.dump(out, f, indent=1)
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0
     assert out["rehearsal_frame_matches_single_rank"] is True
+    assert "gloo" in out["config"]["parallelism"] and "RCCL gather" not in out["config"]["parallelism"]   # say what ran
     assert out["config"]["workload"].startswith("cornell_box.yml 1920x1080 64spp")
+
+
+@pytest.mark.gpu
+def test_rccl_process_group_and_f64_gather_with_one_rank(request, gpu):
+    """`bench.py --force-dist`: backend "nccl" (= RCCL) initialised on the real device, the strips of the frame sent
+    through dist.gather as f64 device tensors, the timings all-reduced; the gathered frame equals a plain render."""
+    proc = getattr(request.config, "_bench_force_dist", None)
+    if proc is None:
+        pytest.skip("started by `pytest -m gpu` (conftest.pytest_sessionstart)")
+    try:
+        stdout, _ = proc.communicate(timeout=900)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        raise
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert proc.returncode == 0 and len(lines) == 1, (proc.returncode, stdout[-2000:],
+                                                      open(os.path.join(ROOT, "gpurun_out", "bench_force_dist.stderr.log")).read()[-3000:])
+    out = json.loads(lines[0])
+    with open(os.path.join(ROOT, "gpurun_out", "bench_force_dist.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    assert out["n_gpus"] == 1 and out["value"] > 0
+    assert out["force_dist"].startswith("backend nccl, world 1")
+    assert "RCCL gather" in out["config"]["parallelism"]
+    assert out["rehearsal_frame_matches_single_rank"] is True
 
 
 @pytest.mark.gpu

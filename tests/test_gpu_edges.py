@@ -327,4 +327,15 @@ def test_many_primitives_through_the_global_memory_bvh(rt, orc, gpu, n):
     if n <= 3000:
         assert d.max() < TOL and (d > TIGHT).mean() < 5e-3
     else:
-        assert (d > TOL).mean() < 0.02
+        assert (d > TOL).mean() < 0.02   # RT_ARITH_FAST: 1-2 ulp amplified by the hall of mirrors flip the odd hit ...
+    # ... and a caller who needs the north-star tolerance on such a scene asks for the reference's arithmetic
+    # (RtSceneOptions.arithmetic): full tolerance on EVERY pixel, the oracle's exact segment count
+    scene = rt.Scene(bundle, arithmetic=abi.RT_ARITH_REFERENCE)
+    try:
+        got = scene.render_frame(camera, params)
+        stats = scene.last_stats()
+    finally:
+        scene.close()
+    d = np.abs(got - ref)
+    assert int(stats.segments) == ref_segs
+    assert d.max() < TOL and (d > TIGHT).mean() < 1e-3

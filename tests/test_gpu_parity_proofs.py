@@ -2,7 +2,7 @@
 
 * closest hit at 20 000 spheres without chaos (max_depth 1, one colour per sphere): any defect of the
   global-memory BVH walk shows as a wrong colour, with the full per-pixel tolerance;
-* the same chaotic hall of mirrors as test_gpu_edges, through the EXACT-arithmetic build of the library
+* the same chaotic hall of mirrors as test_gpu_edges, through RtSceneOptions.arithmetic = RT_ARITH_REFERENCE
   (IEEE divisions, no FMA contraction — the reference's own operations): with the arithmetic difference
   removed the full tolerance must hold, which proves the product build's outliers are arithmetic
   (1-2 ulp of the reciprocal-based divisions amplified by D/r per bounce), not traversal;
@@ -23,7 +23,6 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = 1e-3      # north star: per-channel |delta| < 1e-3
 TIGHT = 1e-9
-EXACT_LIB = os.path.join(ROOT, "racer-tracer_amd", "build", "libracer_tracer_amd_exact.so")
 
 
 @pytest.fixture(scope="module")
@@ -32,9 +31,9 @@ def host():
 
 
 @pytest.fixture(scope="module")
-def exact(rt):
-    assert os.path.exists(EXACT_LIB), "build it with `make -C racer-tracer_amd tests-libs` (or __graft_entry__.build())"
-    return rt.load_library(EXACT_LIB)
+def exact():
+    """RtSceneOptions.arithmetic = RT_ARITH_REFERENCE: what any caller of the C ABI can ask for."""
+    return S.abi.RT_ARITH_REFERENCE
 
 
 def hall_of_spheres(n, one_colour_each):
@@ -93,7 +92,7 @@ def test_hall_of_mirrors_in_exact_arithmetic(rt, orc, gpu, exact, n):
     camera = S.camera_for(cam, w, h)
     params = S.abi.render_params(w, h, spp, max_depth=8)
     ref, ref_segs = orc.render(bundle.desc, camera, params)
-    scene = rt.Scene(bundle, library=exact)
+    scene = rt.Scene(bundle, arithmetic=exact)
     try:
         got = scene.render_frame(camera, params)
         stats = scene.last_stats()
@@ -107,14 +106,14 @@ def test_hall_of_mirrors_in_exact_arithmetic(rt, orc, gpu, exact, n):
 
 
 @pytest.mark.parametrize("scene_fn", [S.three_balls, S.cornell_box_boxes])
-def test_exact_build_agrees_with_product_build(rt, orc, gpu, exact, scene_fn):
-    """The two builds differ only in rounding: same paths, frames equal to ~1e-12 on the shipped scenes."""
+def test_reference_arithmetic_agrees_with_fast_arithmetic(rt, orc, gpu, exact, scene_fn):
+    """The two copies of the kernels differ only in rounding: same paths, frames equal to ~1e-12 on the shipped scenes."""
     bundle, cam, _ = scene_fn()
     camera = S.camera_for(cam, 96, 54)
     params = S.abi.render_params(96, 54, 8)
     frames = []
-    for library in (None, exact):
-        scene = rt.Scene(bundle, library=library)
+    for arithmetic in (S.abi.RT_ARITH_FAST, exact):
+        scene = rt.Scene(bundle, arithmetic=arithmetic)
         try:
             frames.append(scene.render_frame(camera, params))
         finally:

@@ -96,6 +96,8 @@ def collect(bench_args, groups=None, keep_dir=None, log=None):
             log("pmc pass %-6s %s" % (name, "ok" if err is None else err))
         if err is not None:
             stamp["errors"].append("%s: %s" % (name, err))
+            if not stamp["groups"]:  # the very first pass failed (no GPU, no rocprofv3 ...): the others would too
+                break
         if agg is None:
             continue
         stamp["groups"][name] = counters
