@@ -7,6 +7,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <cmath>
 #include <new>
 #include <string>
 #include <vector>
@@ -713,6 +714,10 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
             g.tag = 1;
             if (q.flags != 0 || (q.kind != RT_PRIM_SPHERE && q.kind != RT_PRIM_MOVING_SPHERE)) continue;
             if (q.kind == RT_PRIM_MOVING_SPHERE) {
+                // a MovingSphere with time_a == time_b degenerates by itself in the reference (moving_sphere.rs:37-39:
+                // 0/0); its 1 / (time_b - time_a) = inf must not become the scene-wide interval, where it would turn
+                // the centre of every plain Sphere (dc = 0) into inf * 0 = NaN: it keeps the general path (tag 1)
+                if (!std::isfinite(q.rot_cos)) continue;
                 if (!have_interval) {
                     s->leaf_time_a = q.rot_sin;
                     s->leaf_inv_dt = q.rot_cos;

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "rt_device_types.h"
+#include "rt_bvh_slab.h"
 #include "../../include/rt_abi.h"
 #include "../../include/rt_rng.h"
 
@@ -387,10 +388,8 @@ __device__ __forceinline__ void closest_hit_bvh(const TraceArgs &A, const BvhNod
         if (!(fmax(t_enter, t_min) <= t_exit)) return; // misses the scene's bounds
         if (t_enter > 0.0) t0 = t_enter;
     }
-    const float ofx = (float)(fma(t0, d.x, o.x) - K->bvh_center[0]), ofy = (float)(fma(t0, d.y, o.y) - K->bvh_center[1]),
-                ofz = (float)(fma(t0, d.z, o.z) - K->bvh_center[2]);
-    const float ivx = (float)inv_d.x, ivy = (float)inv_d.y, ivz = (float)inv_d.z;
-    const float oix = ofx * ivx, oiy = ofy * ivy, oiz = ofz * ivz;
+    const SlabRay sr = slab_ray((float)(fma(t0, d.x, o.x) - K->bvh_center[0]), (float)(fma(t0, d.y, o.y) - K->bvh_center[1]),
+                                (float)(fma(t0, d.z, o.z) - K->bvh_center[2]), inv_d.x, inv_d.y, inv_d.z); // rt_bvh_slab.h
     const float slack = 0x1p-20f;
     // the window [t_min, best_t] seen from the clipped origin, rounded outward
     const float tmin_f = (float)(t_min - t0) - fabsf((float)(t_min - t0)) * slack - 0x1p-126f;
@@ -406,12 +405,7 @@ __device__ __forceinline__ void closest_hit_bvh(const TraceArgs &A, const BvhNod
         while (i < n) { // descend / skip until a leaf is entered
             if (walk_stats) ++walk_stats[0]; // profile build: nodes visited
             const BvhNode *N = &nodes[i];
-            const float ax = fmaf(N->mn[0], ivx, -oix), bx = fmaf(N->mx[0], ivx, -oix);
-            const float ay = fmaf(N->mn[1], ivy, -oiy), by = fmaf(N->mx[1], ivy, -oiy);
-            const float az = fmaf(N->mn[2], ivz, -oiz), bz = fmaf(N->mx[2], ivz, -oiz);
-            const float t_near = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin_f));
-            const float t_far = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best_f));
-            if (t_near <= fmaf(fabsf(t_far), slack, t_far)) {
+            if (slab_hit(N->mn, N->mx, sr, tmin_f, best_f, slack)) {
                 const int fc = N->first_count;
                 count = fc & 7;
                 first = fc >> 3;

@@ -1,7 +1,8 @@
 """The device BVH builder (racer-tracer_amd/csrc/rt_bvh.cpp) is host code: tools/sim/bvh_sim.cpp walks the tree it
 builds for the `random` scene on the CPU — by skip links (the device walk), by skip links two nodes at a time and in
-near-to-far order with a stack — over a frame of primary rays and two bounces, and compares every closest hit with a
-linear scan over the primitives."""
+near-to-far order with a stack — over a frame of primary rays, two bounces and a set of axis-parallel rays, and
+compares every closest hit with a linear scan over the primitives.  The box test is the device's own code
+(csrc/rt_bvh_slab.h, f32 fma around the root's centre), compiled for the host."""
 import os
 import re
 import subprocess
@@ -32,6 +33,9 @@ def test_every_walk_finds_the_linear_scan_hit(bvh_sim, max_leaf):
     n_prims, n_nodes, leaves, inner, depth = map(int, head.groups())
     assert n_prims == 485 and leaves == inner + 1 and n_nodes == leaves + inner      # a full binary tree
     assert leaves >= (n_prims + max_leaf - 1) // max_leaf and depth <= 24
+    # axis-parallel rays (direction components of exactly 0, 1/d beyond the f32 range) through the DEVICE's f32 slab test
+    axis = re.search(r"axis-parallel: (\d+) rays, (\d+) hit something \| closest hits differ: (\d+)", out)
+    assert int(axis.group(1)) >= 10000 and int(axis.group(2)) > 1000 and int(axis.group(3)) == 0
     bounces = re.findall(r"bounce (\d): (\d+) rays .* closest hits differ: (\d+)", out)
     assert [b[0] for b in bounces] == ["0", "1", "2"]
     for _, rays, differ in bounces:

@@ -251,3 +251,31 @@ def test_gpu_bvh_leaf_records_with_two_time_intervals(rt, orc, gpu):
     d = np.abs(bvh - ref)
     assert d.max() < 1e-3 and float((d.max(axis=-1) > 1e-9).mean()) < 2e-3
     assert abs(int(st.segments) - ref_segs) <= 4
+
+
+@pytest.mark.gpu
+def test_gpu_bvh_with_axis_parallel_rays(rt, orc, gpu):
+    """Direction components of EXACTLY zero through the f32 culling boxes (1/d = inf: the slab test once formed
+    inf - inf = NaN there and culled the root, so such a ray silently missed the whole scene — rt_bvh_slab.h).
+    An orthographic-style camera does it for every primary ray: `horizontal` only moves the ORIGIN-side corner
+    along x while the direction's x stays 0 (upper_left_corner.x - origin.x == 0 and u * 0 == 0), and with
+    vertical = 0 as well the second camera below makes every primary ray exactly (0, 0, -1)."""
+    bundle, _ = moving_mix_scene(n=120, seed=4)
+    w, h, spp = 96, 54, 4
+    params = abi.render_params(w, h, spp, max_depth=6)
+    for zero_axes in ("x", "xy"):
+        cam = abi.RtCamera()
+        cam.origin = abi.D3(0.25, 1.0, 18.0)
+        cam.upper_left_corner = abi.D3(0.25, 4.0 if zero_axes == "x" else 1.0, 8.0)   # direction = ulc + u*h - v*vert - origin
+        cam.horizontal = abi.D3(0.0, 0.0, 0.0)
+        cam.vertical = abi.D3(0.0, 6.0 if zero_axes == "x" else 0.0, 0.0)
+        cam.right, cam.up, cam.forward = abi.D3(1, 0, 0), abi.D3(0, 1, 0), abi.D3(0, 0, 1)
+        cam.lens_radius, cam.focus_distance, cam.time_a, cam.time_b = 0.0, 10.0, 0.0, 1.0
+        ref, ref_segs = orc.render(bundle.desc, cam, params, use_bvh=0)
+        bvh, st = render_gpu(rt, bundle, cam, params, abi.RT_HIT_BVH)
+        lin, _ = render_gpu(rt, bundle, cam, params, abi.RT_HIT_LINEAR)
+        assert same_frame(bvh, lin), zero_axes
+        d = np.abs(bvh - ref)
+        assert d.max() < 1e-3 and float((d.max(axis=-1) > 1e-9).mean()) < 2e-3, zero_axes
+        assert abs(int(st.segments) - ref_segs) <= 4
+        assert int(st.segments) > w * h * spp * 1.2      # the rays do hit the scene and bounce (a culled root would give sky only)

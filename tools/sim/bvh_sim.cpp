@@ -14,23 +14,54 @@
 #include "rt_abi.h"
 #include "rt_host.h"
 #include "csrc/rt_bvh.h"
+#include "csrc/rt_bvh_slab.h"
 
 struct Ray { double o[3], d[3], time; };
 struct Tree { // binary tree recovered from the skip-link array
     std::vector<int> left, right; // inner: child node indices; leaf: -1
 };
 
-static bool hit_box(const rtdev::BvhNode &n, const double c[3], const Ray &r, double tmax, double &tnear) {
-    double t0 = 0.001, t1 = tmax;
+// The DEVICE's box test (rt_bvh_slab.h: the same code closest_hit_bvh runs): the ray is clipped to the root box in
+// f64, then every node is tested in f32 around the root's centre.  `tnear` (f64, for child ordering only) is a
+// by-product the device walk does not need.
+struct DevRay {
+    rtdev::SlabRay sr;
+    double t0;
+    float tmin_f;
+    bool misses_root;
+};
+static DevRay prepare(const rtdev::BvhBuild &bvh, const Ray &r) { // closest_hit_bvh's prologue
+    DevRay q;
+    double t_enter = -INFINITY, t_exit = INFINITY;
     for (int k = 0; k < 3; ++k) {
         const double inv = 1.0 / r.d[k];
-        double a = ((double)n.mn[k] + c[k] - r.o[k]) * inv, b = ((double)n.mx[k] + c[k] - r.o[k]) * inv;
-        if (a > b) std::swap(a, b);
-        t0 = std::max(t0, a);
-        t1 = std::min(t1, b);
+        const double a = (bvh.root_mn[k] - r.o[k]) * inv, b = (bvh.root_mx[k] - r.o[k]) * inv;
+        t_enter = std::fmax(t_enter, std::fmin(a, b)); // fmin / fmax drop NaNs like the device's
+        t_exit = std::fmin(t_exit, std::fmax(a, b));
+    }
+    q.misses_root = !(std::fmax(t_enter, 0.001) <= t_exit);
+    q.t0 = t_enter > 0.0 ? t_enter : 0.0;
+    q.sr = rtdev::slab_ray((float)(std::fma(q.t0, r.d[0], r.o[0]) - bvh.center[0]), (float)(std::fma(q.t0, r.d[1], r.o[1]) - bvh.center[1]),
+                           (float)(std::fma(q.t0, r.d[2], r.o[2]) - bvh.center[2]), 1.0 / r.d[0], 1.0 / r.d[1], 1.0 / r.d[2]);
+    const float slack = 0x1p-20f;
+    q.tmin_f = (float)(0.001 - q.t0) - std::fabs((float)(0.001 - q.t0)) * slack - 0x1p-126f;
+    return q;
+}
+static const rtdev::BvhBuild *g_bvh = nullptr;
+static bool hit_box(const rtdev::BvhNode &n, const double c[3], const Ray &r, double tmax, double &tnear) {
+    const DevRay q = prepare(*g_bvh, r);
+    if (q.misses_root) return false;
+    const float slack = 0x1p-20f;
+    const float f = (float)(tmax - q.t0);
+    const float best_f = f + std::fabs(f) * slack;
+    double t0 = 0.001;
+    for (int k = 0; k < 3; ++k) { // entry distance in f64, for ordering children only
+        const double inv = 1.0 / r.d[k];
+        const double a = ((double)n.mn[k] + c[k] - r.o[k]) * inv, b = ((double)n.mx[k] + c[k] - r.o[k]) * inv;
+        t0 = std::fmax(t0, std::fmin(a, b));
     }
     tnear = t0;
-    return t0 <= t1;
+    return rtdev::slab_hit(n.mn, n.mx, q.sr, q.tmin_f, best_f, slack);
 }
 static bool hit_prim(const RtPrimitive &p, const Ray &r, double tmax, double &t) {
     double c[3];
@@ -67,6 +98,7 @@ int main(int argc, char **argv) {
     const RtCamera *cam = rth_session_camera(session);
     const int max_leaf = argc > 1 ? atoi(argv[1]) : 4;
     rtdev::BvhBuild bvh = rtdev::build_bvh(d->primitives, d->n_primitives, max_leaf);
+    g_bvh = &bvh;
     printf("max %d primitives per leaf: ", max_leaf);
     const int n = (int)bvh.nodes.size();
     Tree tree;
@@ -209,6 +241,31 @@ int main(int argc, char **argv) {
         }
         return steps;
     };
+    { // axis-parallel rays: direction components of exactly 0 (1/d = inf).  The f32 slab test once turned these into
+      // inf - inf = NaN and culled the root (rt_bvh_slab.h: slab_finite); every hit must be the linear scan's.
+        std::uniform_real_distribution<double> X(-12.0, 12.0), Y(0.05, 2.5);
+        long differ = 0, hits = 0;
+        const int n_axis = 12000;
+        for (int k = 0; k < n_axis; ++k) {
+            Ray r;
+            r.o[0] = X(rng); r.o[1] = Y(rng); r.o[2] = X(rng);
+            const int axis = k % 3, kind = (k / 3) % 4;
+            for (int j = 0; j < 3; ++j) r.d[j] = 0.0;
+            r.d[axis] = (k & 8) ? 1.0 : -1.0;                        // kind 0: two zero components
+            if (kind == 1) r.d[(axis + 1) % 3] = U(rng) - 0.5;       // one zero component
+            if (kind == 2) r.d[(axis + 2) % 3] = -0.0;               // a negative zero among them
+            if (kind == 3) { r.d[axis] = 1e-300; r.d[(axis + 1) % 3] = (k & 8) ? 1.0 : -1.0; } // 1/d beyond the f32 range
+            if (k % 7 == 0) { r.o[0] = std::round(r.o[0]); r.o[2] = std::round(r.o[2]); }      // origins ON lattice planes
+            r.time = U(rng);
+            Count c;
+            int bs, bl;
+            walk_skip(r, c, bs);
+            closest_linear(r, bl);
+            differ += bs != bl;
+            hits += bl >= 0;
+        }
+        printf("axis-parallel: %d rays, %ld hit something | closest hits differ: %ld\n", n_axis, hits, differ);
+    }
     // NOTE the ordered walk re-tests a popped node's box implicitly never: a popped far child may have become
     // prunable (best_t shrank); count that variant too
     for (int bounce = 0; bounce < 3; ++bounce) {
