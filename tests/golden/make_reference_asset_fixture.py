@@ -15,6 +15,9 @@ PIL (nothing from the reference is executed) and stores
     150x150 or 75x75 pixels of a 200-spp image, so its mean carries next to no Monte Carlo
     noise; clown.yml and three_balls.yml are fully deterministic scenes, noise_and_textures.yml
     outside its randomly seeded Perlin sphere too);
+  * for noise_and_textures.png additionally the CONTRAST of every 8x8 block (standard deviation of its 5x5-pixel cell
+    means): with the block mean it pins the statistics of the randomly seeded Perlin marble (octaves, turbulence weight,
+    sine phase), whose individual values no fixed table can reproduce;
   * for emissive.png, whose lights are brighter than the shipped emissive.yml's (the screenshot
     predates the scene file, like cornell_box.png) and whose every diffuse surface is a randomly
     seeded Noise texture: where its two lights ARE — per-row and per-column counts of saturated
@@ -55,6 +58,20 @@ def main():
         out["block_means"][name] = np.round(bm, 5).tolist()
         bm8 = img.reshape(8, 75, 8, 75, 3).mean(axis=(1, 3))
         out["block_means_8x8"][name] = np.round(bm8, 5).tolist()
+    # texture CONTRAST inside a block, for the randomly seeded marble of noise_and_textures.png: the standard deviation,
+    # per channel, of the 15x15 means of 5x5-pixel cells of each 75x75 block (cell means carry 1/5 of a pixel's Monte
+    # Carlo noise, so what is left is the texture's own variation)
+    img = np.array(Image.open(os.path.join(REF, "assets", "noise_and_textures.png")).convert("RGB")).astype(np.float64) / 255.0
+    cells = img.reshape(8, 15, 5, 8, 15, 5, 3).mean(axis=(2, 5))           # [block y, cell y, block x, cell x, rgb]
+    out["block_cell_stds_8x8"] = {"noise_and_textures": np.round(cells.std(axis=(1, 3)), 5).tolist()}
+    # ... and of the 140x140-pixel square inscribed in the marble sphere's disc (projected centre (319.5, 273.8), radius
+    # 107 px; the square's half diagonal is 99): mean and contrast at four cell sizes — how the variation is spread
+    # over spatial frequencies is what the octave count and the noise scale decide
+    x0, y0, size = 250, 204, 140
+    patch = img[y0:y0 + size, x0:x0 + size]
+    out["marble_patch"] = {"x0": x0, "y0": y0, "size": size, "mean": np.round(patch.mean(axis=(0, 1)), 5).tolist(),
+                           "cell_std": {str(c): np.round(patch.reshape(size // c, c, size // c, c, 3).mean(axis=(1, 3)).std(axis=(0, 1)), 5).tolist()
+                                        for c in (5, 10, 20, 35)}}
     em = np.array(Image.open(os.path.join(REF, "assets", "emissive.png")).convert("RGB")).astype(int)
     lit = (em >= 250).all(axis=-1)            # both lights saturate in the screenshot: (255, 255, 254) / (255, 255, 255)
     black = (em == 0).all(axis=-1)

@@ -183,3 +183,28 @@ def test_gpu_reproduces_noise_and_textures_outside_the_marble_sphere(rt, host, g
             checked += 1
             assert d8[by, bx] < 0.012, (by, bx, d8[by, bx])
     assert checked >= 48 and d8[[0, 1, 6, 7]].max() < 0.003
+
+
+def test_gpu_marble_statistics_of_the_reference_png_lie_inside_the_seed_envelope(rt, host, gpu):
+    """The value side of the Noise texture on the DEVICE (wave-cooperative turbulence, lean sin, LDS gradient table):
+    eight Perlin seeds rendered, tone-mapped and packed on the GPU; the screenshot's marble statistics must lie
+    inside their envelope, and a render without the sine's z phase / with a wrong scale outside it
+    (tests/noise_stats.py: what this pins, and that octaves 3-7 stay below what the screenshot shows)."""
+    import noise_stats as N
+
+    def stats(session):
+        p = session.params
+        p.samples = 64
+        dev = rt.Scene(session)
+        try:
+            rgba = dev.render_frame_rgba8(session.camera, p, session.tone_map_desc)
+        finally:
+            dev.close()
+        return N.patch_stats(rgba[..., :3].astype(np.float64) / 255.0)
+
+    seeds = np.array([stats(N.noise_session(host, seed)) for seed in range(1, 9)])
+    ref = N.reference_stats()
+    ok = N.inside_envelope(ref, seeds)
+    assert ok.all(), (ref[~ok], seeds.min(axis=0)[~ok], seeds.max(axis=0)[~ok])
+    assert not N.inside_envelope(stats(N.noise_session(host, 1, scale=0.0)), seeds)[:3].any()
+    assert not N.inside_envelope(stats(N.noise_session(host, 2, scale=12.0)), seeds)[-3:].any()
