@@ -268,11 +268,16 @@ def host_delivery(rt, scene, session, reps=5):
     p.strip_count = 0
     W, H = p.width, p.height
     frame = np.zeros((H, W, 3), dtype=np.float64)
+    # one buffer per tile, filled by a plain memcpy inside the callback — what `rgb.to_vec()` costs a Rust binding
+    # (INTEGRATION.md section 3); the reference's own tiles are moved, not copied (cpu.rs:64-70)
+    tile_bytes = (W // p.tiles_w + W % p.tiles_w) * (H // p.tiles_h + H % p.tiles_h) * 24
+    store = np.zeros((p.tiles_w * p.tiles_h, tile_bytes), dtype=np.uint8)
+    slots = [store[i].ctypes.data for i in range(store.shape[0])]
     tiles = []
 
     def on_tile(_user, rgb, r, c, w, h):
-        frame[r:r + h, c:c + w] = np.ctypeslib.as_array(rgb, shape=(h, w, 3))
-        tiles.append(1)
+        C.memmove(slots[len(tiles)], rgb, w * h * 24)
+        tiles.append((r, c, w, h))
 
     cb = abi.RtTileCallback(on_tile)
     lib = rt.lib()

@@ -270,6 +270,8 @@ void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtd
 
 } // namespace
 
+int rtapi::chunk_count(int samples) { return (int)chunk_plan(samples).size() - 1; }
+
 int rtapi::owned_rows_of(const RtRenderParams *p) {
     if (p->strip_count <= 1) return p->height;
     int owned_strips = 0; // strips j with first row (j*count + index)*rows inside the image

@@ -165,9 +165,16 @@ int deliver_frame(RtScene *const *scenes, int n, const RtCamera *camera, const R
     int most_bands = 0;
     for (Share &sh : shares) {
         const int tile_rows = (rtapi::owned_rows_of(&sh.params) + 7) / 8;
-        // bands of at least two tile rows (a band must outnumber the resident waves to keep them busy across its end)
-        int bands = tile_rows / 2;
+        // How many bands?  The launch ends on the LAST band's last chunks — (tiles of the band) x (a few chunks) items for
+        // thousands of resident waves — so a small last band costs an unbalanced tail of about one item's duration,
+        // while a large one costs the copy of its rows after the GPU is done.  Items are short when a frame has many
+        // chunks (C3: 19 chunks, 0.2 ms items: 32 bands, +0.8 ms in all) and long when it has few (64 spp of a
+        // 485-sphere scene: 4 chunks, 1.6 ms items: 32 bands cost +3.5 ms, 8 bands +1.x): two bands per chunk.
+        int bands = tile_rows / 2; // at least two tile rows each
+        const int by_chunks = 2 * rtapi::chunk_count(sh.params.samples);
+        if (bands > by_chunks) bands = by_chunks < 4 ? 4 : by_chunks;
         if (bands > rtdev::RT_MAX_REGIONS) bands = rtdev::RT_MAX_REGIONS;
+        if (bands > tile_rows) bands = tile_rows;
         if (bands < 1) bands = 1;
         for (int b = 0; b < bands; ++b) {
             rtdev::Region reg;

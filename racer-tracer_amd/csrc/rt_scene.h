@@ -132,6 +132,8 @@ inline int owned_row_to_image_row(const RtRenderParams *p, int vr) {
     if (p->strip_count <= 1) return vr;
     return ((vr / p->strip_rows) * p->strip_count + p->strip_index) * p->strip_rows + vr % p->strip_rows;
 }
+// Sample chunks a frame of `samples` samples per pixel is cut into (a function of spp only: rt_api.hip: chunk_plan).
+int chunk_count(int samples);
 // Rows of the owned-row grid of a render with these parameters (a multiple of strip_rows with strips).
 int owned_rows_of(const RtRenderParams *p);
 } // namespace rtapi

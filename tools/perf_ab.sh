@@ -10,7 +10,7 @@ for kv in "$@"; do
   case "$kv" in RT_*) [ -z "$RACER_TRACER_AMD_LIB" ] && export RACER_TRACER_AMD_LIB=$(dirname "$0")/../racer-tracer_amd/build/libracer_tracer_amd_dev.so;; esac
 done
 for w in ${WORKLOADS:-c3 c2 c4}; do
-  timeout -k 10 90 python3 bench.py --workload $w --no-cpu-baseline --steps 3 --warmup 1 2>/dev/null | python3 -c "
+  timeout -k 10 90 python3 bench.py --workload $w --no-cpu-baseline --pmc none --no-host-delivery --steps 3 --warmup 1 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('$tag $w %.0f Msamples/s  %.2f ms  %.2f Gseg/s' % (d['value'], d['ms_per_step'], d['roofline']['gsegments_per_s']))"

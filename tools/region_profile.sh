@@ -11,5 +11,5 @@ lib=$PWD/racer-tracer_amd/build/libracer_tracer_amd_regions.so
 [ -f "$lib" ] || { echo "missing $lib (make -C racer-tracer_amd profile-lib)"; exit 1; }
 for w in ${@:-c3 c2 c4}; do
   echo "== $w"
-  RACER_TRACER_AMD_LIB=$lib timeout -k 10 120 python3 bench.py --workload $w --no-cpu-baseline --steps 1 --warmup 1 2>&1 | grep -E "^region" || true
+  RACER_TRACER_AMD_LIB=$lib timeout -k 10 120 python3 bench.py --workload $w --no-cpu-baseline --pmc none --no-host-delivery --steps 1 --warmup 1 2>&1 | grep -E "^region" || true
 done
