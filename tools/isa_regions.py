@@ -18,7 +18,7 @@ NAMES = {0: "item setup", 1: "batches", 2: "hand-out + primary ray", 3: "closest
 def main():
     want = sys.argv[1] if len(sys.argv) > 1 else "Li0ELb0ELb0ELb0E"
     lines = open(LISTING).read().split("\n")
-    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN5rtdev16k_trace_pool_f64I" + want))
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN10rtdev_fast16k_trace_pool_f64I" + want))
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
     seg = collections.Counter()
     kinds = collections.defaultdict(collections.Counter)
