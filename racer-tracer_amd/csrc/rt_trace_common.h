@@ -224,6 +224,7 @@ struct Hit {
     d3 point, normal;
     double u, v;
     bool front;
+    bool uv_approx; // u, v come from sphere_uv_f32: good to UV_EPS_U / UV_EPS_V, to be certified by whoever reads them
 };
 
 __device__ __forceinline__ void set_face_normal(Hit &h, d3 dir, d3 outward) { // geometry.rs:49-56
@@ -471,8 +472,27 @@ __device__ __noinline__ UV sphere_uv(d3 outward) {
 #endif
 }
 
+// sphere.rs:20-27 in SINGLE precision, for the one consumer of a sphere's (u, v): the nearest-texel lookup of an image
+// texture (texture/image.rs:28-51), which only asks which cell of a w x h grid (u, v) falls into.  acos + atan2 in f64 are
+// ~250 vector instructions at 4 cycles, run for the handful of lanes of a wave that hit the textured sphere (C4: 6 % of
+// the frame); in f32 they are ~70 at 2 cycles.  The result is within UV_EPS_U / UV_EPS_V of the exact pair — inputs
+// rounded to f32 (6e-8 relative), acosf / atan2f good to a few ulp of pi (5e-7), the rest in f64 — PROVIDED the point is
+// not near a pole, where acos' derivative 1 / sqrt(1 - y^2) amplifies the input rounding: the caller keeps the f64 form
+// for 1 - y^2 < 2^-10.  image_texel() certifies every use: when a cell boundary lies within the bound of the value it
+// recomputes (u, v) exactly, so the texel — hence the frame — is the one the f64 form selects, bit for bit.
+#define RT_UV_EPS_U 5e-7
+#define RT_UV_EPS_V 2e-6
+__device__ __forceinline__ UV sphere_uv_f32(d3 outward) {
+    const float theta = acosf(-(float)outward.y);
+    const float phi = atan2f(-(float)outward.z, (float)outward.x);
+    return UV{((double)phi + 3.14159265358979323846) * (1.0 / (2.0 * 3.14159265358979323846)),
+              (double)theta * (1.0 / 3.14159265358979323846)};
+}
+
 // Rebuild the HitRecord of the winning primitive (geometry.rs:17-57).
-template <int PRIMS, bool TEXTURED>
+// FAST_UV: a plain sphere's (u, v) may come from sphere_uv_f32 (Hit.uv_approx says so); the pooled kernel's texture code
+// certifies it, the v1 kernel keeps the f64 form.
+template <int PRIMS, bool TEXTURED, bool FAST_UV = false>
 __device__ __forceinline__ Hit prim_hit_record(const Prim &P, d3 o, d3 d, double time, double t, int aux, bool want_uv) {
     d3 oo = o, dd = d;
     const int flags = PRIMS == PRIMS_ANY ? P.flags : 0;
@@ -485,6 +505,7 @@ __device__ __forceinline__ Hit prim_hit_record(const Prim &P, d3 o, d3 d, double
     h.point = oo + t * dd; // ray.rs:30-32
     h.u = 0.0;
     h.v = 0.0;
+    h.uv_approx = false;
     const int kind = PRIMS == PRIMS_SPHERES ? (int)RT_PRIM_SPHERE : P.kind;
     if (PRIMS == PRIMS_ANY && kind == RT_PRIM_MOVING_SPHERE) {
         const d3 center = ld3(P.p) + ((time - P.rot_sin) * P.rot_cos) * ld3(P.tr);
@@ -498,9 +519,20 @@ __device__ __forceinline__ Hit prim_hit_record(const Prim &P, d3 o, d3 d, double
     } else if (PRIMS != PRIMS_RECTS && kind == RT_PRIM_SPHERE) {
         d3 outward = (h.point - ld3(P.p)) * P.inv_radius; // sphere.rs:61
         if (TEXTURED && want_uv) {
-            const UV uv = sphere_uv(outward);
-            h.u = uv.u;
-            h.v = uv.v;
+#ifndef RT_EXACT_DIV
+            // unwrapped sphere away from the poles: f32 now, certified (or redone in f64) where it is used
+            if (FAST_UV && flags == 0 && fma(-outward.y, outward.y, 1.0) >= 0x1p-10) {
+                const UV uv = sphere_uv_f32(outward);
+                h.u = uv.u;
+                h.v = uv.v;
+                h.uv_approx = true;
+            } else
+#endif
+            {
+                const UV uv = sphere_uv(outward);
+                h.u = uv.u;
+                h.v = uv.v;
+            }
         }
         set_face_normal(h, dd, outward);
     } else {
@@ -667,8 +699,30 @@ __device__ __forceinline__ d3 texture_value_full(const TraceArgs &A, const Perli
 // notes WHICH one (`noise_tex`, after a Checkered parent has picked its side) and returns zeros.
 // Step 2 (whole wave, coop_noise_turbulence in rt_trace_pool_kernel.hip) evaluates the turbulence of all
 // noted lookups together, and noise_colour() finishes noise.rs:26-33.
+// texture/image.rs:28-51: the cell of a width x height grid that (u, v) selects (v flipped, both clamped)
+__device__ __forceinline__ void image_cell(double u, double v, int width, int height, uint32_t &xi, uint32_t &yj) {
+    const double uu = clamp01(u);
+    const double vv = 1.0 - clamp01(v);
+    double i = uu * (double)width;
+    double j = vv * (double)height;
+    if (i >= (double)width) i = (double)width - 1.0;
+    if (j >= (double)height) j = (double)height - 1.0;
+    xi = (uint32_t)i; // saturating, NaN -> 0
+    yj = (uint32_t)j;
+}
+// Is a cell boundary within +-eps_u / +-eps_v of (u, v)?  (Only then can an approximate pair select another cell
+// than the exact one; the clamps are monotone, so they cannot create a difference that the unclamped grid does not have.)
+__device__ __forceinline__ bool image_cell_uncertain(double u, double v, int width, int height) {
+    const double iu = u * (double)width, jv = v * (double)height;
+    const double fu = iu - floor(iu), fv = jv - floor(jv);
+    const double mu = RT_UV_EPS_U * (double)width, mv = RT_UV_EPS_V * (double)height;
+    return fu < mu || fu > 1.0 - mu || fv < mv || fv > 1.0 - mv;
+}
+
+// uv_approx: (u, v) are sphere_uv_f32's; `exact_uv()` recomputes them in f64 (called only when a lookup cannot be certified)
+template <class ExactUV>
 __device__ __forceinline__ d3 texture_value_deferred(const TraceArgs &A, const Texture *textures, int ti, double u, double v,
-                                                     d3 p, int &noise_tex) {
+                                                     d3 p, int &noise_tex, bool uv_approx, ExactUV exact_uv) {
     const Texture *T = &textures[ti];
     if (T->kind == RT_TEX_CHECKERED) { // checkered.rs:32-42
         const int sines = sin_sign(p.x * 10.0) * sin_sign(p.y * 10.0) * sin_sign(p.z * 10.0);
@@ -678,13 +732,13 @@ __device__ __forceinline__ d3 texture_value_deferred(const TraceArgs &A, const T
     const int kind = T->kind;
     if (kind == RT_TEX_IMAGE) { // texture/image.rs:28-51
         const int width = T->img.width, height = T->img.height;
-        const double uu = clamp01(u);
-        const double vv = 1.0 - clamp01(v);
-        double i = uu * (double)width;
-        double j = vv * (double)height;
-        if (i >= (double)width) i = (double)width - 1.0;
-        if (j >= (double)height) j = (double)height - 1.0;
-        const uint32_t xi = (uint32_t)i, yj = (uint32_t)j; // saturating, NaN -> 0
+        if (uv_approx && image_cell_uncertain(u, v, width, height)) { // a cell boundary within the f32 pair's error: redo in f64
+            const UV e = exact_uv();
+            u = e.u;
+            v = e.v;
+        }
+        uint32_t xi, yj;
+        image_cell(u, v, width, height, xi, yj);
         const uchar4 px = reinterpret_cast<const uchar4 *>(T->img.rgba)[(size_t)yj * (size_t)width + xi];
         const double s = 1.0 / 255.0;
         return mk((double)px.x * s, (double)px.y * s, (double)px.z * s);

@@ -801,7 +801,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                     } else {
                         const Prim &P = BVH ? A.prims[best] : lds_prims[best];
                         const Material &M = P.mat;
-                        const Hit h = prim_hit_record<PRIMS, TEXTURED>(P, o, d, ray_time, best_t, best_aux, M.needs_uv != 0);
+                        const Hit h = prim_hit_record<PRIMS, TEXTURED, true>(P, o, d, ray_time, best_t, best_aux, M.needs_uv != 0);
                         const int kind = M.kind;
                         RT_REGION(8); // hit record
 #ifdef RT_PROFILE_REGIONS
@@ -820,7 +820,9 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                         if (!SPECULAR || kind != RT_MAT_DIELECTRIC) {
                             d3 tex;
                             if (!TEXTURED || M.tex_kind == RT_TEX_SOLID_COLOR) tex = ld3(M.color); // solid_color.rs:24-28
-                            else tex = texture_value_deferred(A, BVH ? A.textures : lds_textures, M.texture, h.u, h.v, h.point, noise_tex);
+                            else tex = texture_value_deferred(A, BVH ? A.textures : lds_textures, M.texture, h.u, h.v, h.point, noise_tex, h.uv_approx,
+                                                              // sphere.rs:20-27 in f64 from the outward normal (the face normal, un-flipped: exact)
+                                                              [&] { return sphere_uv(h.front ? h.normal : -h.normal); });
                             // emission (the path ends) or attenuation, one copy for all three; a Noise colour arrives below
                             if (!TEXTURED || noise_tex < 0) T = T * tex;
                         }
