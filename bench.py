@@ -334,6 +334,7 @@ def spawn_ranks(args):
 
 
 def main():
+    t_start = time.time()
     args = parse()
     if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))  # before torch / HIP are even imported
@@ -341,6 +342,7 @@ def main():
     live_summary, live_why_not = (None, "--pmc %s" % args.pmc)
     if args.pmc == "live":
         live_summary, live_why_not = live_pmc_summary(args)
+    t_pmc = time.time() - t_start
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -496,12 +498,19 @@ def main():
                 out["roofline"]["traffic_frac_of_hbm_peak"] = round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         else:
             out["roofline"]["counters_unavailable"] = why_not
+        t_host = time.time()
         if world == 1 and dist is None and not args.no_host_delivery:
             out["host_delivered"] = host_delivery(rt, scene, session)
             out["host_delivered"]["vs_device_resident"] = {
                 k: round(out["host_delivered"][k]["ms"] / ms_per_step, 4) for k in ("rt_render", "rt_render_frame")}
+        t_host = time.time() - t_host
+        t_cpu = time.time()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(session, args.cpu_seconds)
+        # where the wall time of this command went (the timed region is `steps` x `ms_per_step`; the rest is evidence)
+        out["wall_s"] = {"live_counter_passes": round(t_pmc, 1), "timed_region": round(elapsed, 2),
+                         "host_delivery_calls": round(t_host, 1), "cpu_baseline": round(time.time() - t_cpu, 1),
+                         "total": round(time.time() - t_start, 1)}
         if rehearsal:
             out["rehearsal"] = "N ranks on ONE GPU over gloo: functional check only"
         if args.force_dist:

@@ -31,7 +31,7 @@ struct Share {
 };
 
 int render_multi(RtScene *const *scenes, int n, const RtCamera *camera, const RtRenderParams *p, int strip_rows,
-                 double *out, bool out_on_device) {
+                 double *out) {
     if (!scenes || n <= 0) return fail(RT_ERR_INVALID_ARGUMENT, "no scenes");
     for (int i = 0; i < n; ++i)
         if (!scenes[i]) return fail(RT_ERR_INVALID_ARGUMENT, "scenes[" + std::to_string(i) + "] is NULL");
@@ -72,7 +72,7 @@ int render_multi(RtScene *const *scenes, int n, const RtCamera *camera, const Rt
             sh.params.strip_index = i;
         }
         RT_HIP(hipSetDevice(sh.scene->device));
-        sh.in_place = out_on_device && sh.scene->device == dst_device;
+        sh.in_place = sh.scene->device == dst_device;
         if (sh.in_place) {
             sh.target = out;
         } else {
@@ -83,12 +83,8 @@ int render_multi(RtScene *const *scenes, int n, const RtCamera *camera, const Rt
         drain.launched.push_back(sh.scene);
         if (rc != RT_OK) return rc;
     }
-    // 2. every device sends its own strips, behind its resolve pass on its own stream
-    bool registered = false;
-    if (!out_on_device && n > 1) // pinned for the duration of the call: the D2H copies of all devices then overlap
-        registered = hipHostRegister(out, n_elems * sizeof(double), hipHostRegisterPortable) == hipSuccess;
-    if (!registered) (void)hipGetLastError();
-    if (out_on_device && n > 1) {
+    // 2. every other device sends its own strips to device 0, behind its resolve pass on its own stream
+    if (n > 1) {
         for (int i = 0; i < n; ++i) {
             const int dev = scenes[i]->device;
             if (dev == dst_device) continue;
@@ -116,14 +112,11 @@ int render_multi(RtScene *const *scenes, int n, const RtCamera *camera, const Rt
             const int rows = (r0 + strip_rows <= p->height ? strip_rows : p->height - r0) ;
             const size_t off = (size_t)r0 * row_elems, bytes = (size_t)rows * row_elems * sizeof(double);
             hipError_t e;
-            if (n == 1) { // one share: the whole frame in one copy
-                e = out_on_device ? hipMemcpyPeerAsync(out, dst_device, sh.target, sh.scene->device, n_elems * sizeof(double), sh.scene->stream)
-                                  : hipMemcpyAsync(out, sh.target, n_elems * sizeof(double), hipMemcpyDeviceToHost, sh.scene->stream);
+            if (n == 1) { // one share (on another device than the output): the whole frame in one copy
+                e = hipMemcpyPeerAsync(out, dst_device, sh.target, sh.scene->device, n_elems * sizeof(double), sh.scene->stream);
                 j = n_strips;
-            } else if (out_on_device) {
-                e = hipMemcpyPeerAsync(out + off, dst_device, sh.target + off, sh.scene->device, bytes, sh.scene->stream);
             } else {
-                e = hipMemcpyAsync(out + off, sh.target + off, bytes, hipMemcpyDeviceToHost, sh.scene->stream);
+                e = hipMemcpyPeerAsync(out + off, dst_device, sh.target + off, sh.scene->device, bytes, sh.scene->stream);
             }
             if (e != hipSuccess) {
                 first_error = fail(RT_ERR_HIP, std::string("strip copy: ") + hipGetErrorString(e));
@@ -136,7 +129,6 @@ int render_multi(RtScene *const *scenes, int n, const RtCamera *camera, const Rt
         if (hipSetDevice(scenes[i]->device) != hipSuccess || hipStreamSynchronize(scenes[i]->stream) != hipSuccess)
             if (first_error == RT_OK) first_error = fail(RT_ERR_HIP, "stream synchronisation failed on share " + std::to_string(i));
     }
-    if (registered) (void)hipHostUnregister(out);
     return first_error;
 }
 
@@ -147,7 +139,7 @@ extern "C" {
 int rt_render_frame_multi_device(RtScene *const *scenes, int n_scenes, const RtCamera *camera,
                                  const RtRenderParams *params, int strip_rows, double *out_rgb_device) {
     try {
-        return render_multi(scenes, n_scenes, camera, params, strip_rows, out_rgb_device, true);
+        return render_multi(scenes, n_scenes, camera, params, strip_rows, out_rgb_device);
     } catch (const std::exception &e) {
         return fail(RT_ERR_OUT_OF_MEMORY, std::string("rt_render_frame_multi_device: ") + e.what());
     }

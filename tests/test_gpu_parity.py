@@ -153,8 +153,8 @@ def test_cancel_during_render_returns_ok_and_stops_the_tile_stream(rt, orc, gpu)
     """cpu.rs:55-62: a cancel seen while rendering makes render() return Ok(());
     tiles that finished before it stay written, nothing is written afterwards.
     rt_render delivers tile columns as they finish; the host polls the flag
-    before every launch and callback and while it waits, the waves in flight
-    stop at their next item once it is up."""
+    before every callback and while it waits, the waves in flight stop at their
+    next item once it is up."""
     import ctypes as C
     import threading
     import time
@@ -217,10 +217,10 @@ def test_cancel_during_render_returns_ok_and_stops_the_tile_stream(rt, orc, gpu)
 
 @pytest.mark.parametrize("w,h,tw,th", [(101, 47, 7, 3), (64, 36, 2, 2), (50, 30, 1, 4), (37, 23, 10, 10), (9, 9, 12, 2)])
 def test_progressive_tiles_are_bit_identical_to_the_frame(rt, orc, gpu, w, h, tw, th):
-    """Tile columns are traced in their own launches (column windows of the item
-    grid) and delivered while the next column renders; every pixel must still be
-    the whole-frame render's pixel bit for bit, in cpu.rs:73-115's order, with and
-    without a cancel flag."""
+    """Tile columns are regions of ONE delivering launch (column windows of the item grid,
+    racer-tracer_amd/csrc/rt_deliver.hip) and are handed over while the next column renders;
+    every pixel must still be the whole-frame render's pixel bit for bit, in cpu.rs:73-115's
+    order, with and without a cancel flag."""
     import ctypes as C
     bundle, cam, _ = S.cornell_box_boxes()
     spp = 40
