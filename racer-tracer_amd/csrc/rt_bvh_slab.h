@@ -42,12 +42,30 @@ RT_SLAB_FN SlabRay slab_ray(float ofx, float ofy, float ofz, double inv_dx, doub
 
 // Does the ray's window [tmin_f, best_f] (seen from the clipped origin, already rounded outward) overlap the box?
 // `slack` is the relative slack of the interval test (2^-20: the f32 plane distances are good to 2^-23 relative).
+// On the device the minima and maxima are written as the instructions themselves: through fminf / fmaxf the compiler
+// re-canonicalises the loop-carried window ends (v_max_f32 x, x) on EVERY node, two of the step's 26 vector
+// instructions, because it cannot prove them free of signalling NaNs.  v_min / v_max return the non-NaN operand like
+// fminf / fmaxf do, so the host form below is the same function.
 RT_SLAB_FN bool slab_hit(const float mn[3], const float mx[3], const SlabRay &r, float tmin_f, float best_f, float slack) {
     const float ax = fmaf(mn[0], r.ivx, -r.oix), bx = fmaf(mx[0], r.ivx, -r.oix);
     const float ay = fmaf(mn[1], r.ivy, -r.oiy), by = fmaf(mx[1], r.ivy, -r.oiy);
     const float az = fmaf(mn[2], r.ivz, -r.oiz), bz = fmaf(mx[2], r.ivz, -r.oiz);
+#if defined(__HIP_DEVICE_COMPILE__)
+    float nx, ny, nz, fx, fy, fz, t_near, t_far;
+    asm("v_min_f32 %0, %1, %2" : "=v"(nx) : "v"(ax), "v"(bx));
+    asm("v_max_f32 %0, %1, %2" : "=v"(fx) : "v"(ax), "v"(bx));
+    asm("v_min_f32 %0, %1, %2" : "=v"(ny) : "v"(ay), "v"(by));
+    asm("v_max_f32 %0, %1, %2" : "=v"(fy) : "v"(ay), "v"(by));
+    asm("v_min_f32 %0, %1, %2" : "=v"(nz) : "v"(az), "v"(bz));
+    asm("v_max_f32 %0, %1, %2" : "=v"(fz) : "v"(az), "v"(bz));
+    asm("v_max_f32 %0, %1, %2" : "=v"(nz) : "v"(nz), "v"(tmin_f));
+    asm("v_min_f32 %0, %1, %2" : "=v"(fz) : "v"(fz), "v"(best_f));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t_near) : "v"(nx), "v"(ny), "v"(nz));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t_far) : "v"(fx), "v"(fy), "v"(fz));
+#else
     const float t_near = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin_f));
     const float t_far = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best_f));
+#endif
     return t_near <= fmaf(fabsf(t_far), slack, t_far);
 }
 
