@@ -206,3 +206,38 @@ def test_whole_frame_over_several_scenes_matches(rt, gpu):
     finally:
         for s in scenes:
             s.close()
+
+
+def test_paths_that_do_not_deliver_still_stream_tiles(rt, gpu):
+    """The v1 kernel and the preview scale render with the two-pass path and cut the tiles from the finished frame
+    (rt_deliver.hip: tiles_from_frame): same tiles, the cancel callback honoured; several devices refuse them."""
+    bundle, cam, _ = S.three_balls()
+    w, h = 96, 54
+    camera = S.camera_for(cam, w, h)
+    params = S.abi.render_params(w, h, 6, tiles_w=4, tiles_h=3)
+    v1 = rt.Scene(bundle, kernel=S.abi.RT_KERNEL_V1)
+    pool = rt.Scene(bundle)
+    try:
+        frame = v1.render_frame(camera, params)
+        polls = []
+        tiles = v1.render_tiles(camera, params, cancel=lambda: polls.append(1) and False)
+        assert len(tiles) == 12 and len(polls) >= 12
+        for r, c, tw, th, arr in tiles:
+            assert np.array_equal(arr, frame[r:r + th, c:c + tw])
+        count = [0]
+
+        def fires_on_the_sixth_poll():   # not on entry (that would be RT_ERR_CANCEL_EVENT): somewhere inside the call
+            count[0] += 1
+            return count[0] > 5
+
+        cut = v1.render_tiles(camera, params, cancel=fires_on_the_sixth_poll)
+        assert len(cut) < 12 and [t[:4] for t in cut] == [t[:4] for t in tiles[:len(cut)]]
+        with pytest.raises(rt.RtError) as e:
+            rt.render_tiles_multi([v1, pool], camera, params)
+        assert e.value.code == S.abi.RT_ERR_UNSUPPORTED
+        preview = S.abi.render_params(w, h, 6, tiles_w=4, tiles_h=3, scale=3)
+        with pytest.raises(rt.RtError):
+            rt.render_tiles_multi([pool, rt.Scene(bundle)], camera, preview)
+    finally:
+        v1.close()
+        pool.close()
