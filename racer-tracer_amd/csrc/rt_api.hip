@@ -29,7 +29,7 @@
     extern "C" hipError_t rtdev_launch_resolve_chunks##SUFFIX(const double *partial, double *out, int width, int height,  \
                                                               int n_chunks, int strip_rows, int strip_count,              \
                                                               int strip_index, int step_x, int step_y, int cover_w,       \
-                                                              int cover_h, int x0, int x_count, int samples,              \
+                                                              int cover_h, int out_col_step, int out_cols, int samples,   \
                                                               hipStream_t stream);
 RT_DECLARE_LAUNCHERS()
 RT_DECLARE_LAUNCHERS(_exact)
@@ -280,7 +280,8 @@ int rtapi::owned_rows_of(const RtRenderParams *p) {
 }
 
 int rtapi::enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, double *out_device,
-                          hipStream_t stream, int batch, const Cancel &cancel, const Delivery *delivery) {
+                          hipStream_t stream, int batch, const Cancel &cancel, const Delivery *delivery, int out_col_step,
+                          int out_cols) {
     RT_HIP(hipSetDevice(s->device));
     size_t n = (size_t)p->width * (size_t)p->height * 3;
     rtdev::TraceArgs a;
@@ -289,7 +290,7 @@ int rtapi::enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderPara
     int launches = 0;
     if (s->use_v1) {
         if (p->scale > 1) return fail(RT_ERR_UNSUPPORTED, "the v1 kernel has no preview mode");
-        if (delivery) return fail(RT_ERR_UNSUPPORTED, "the v1 kernel does not deliver its own pixels");
+        if (delivery || out_cols > 1) return fail(RT_ERR_UNSUPPORTED, "the v1 kernel does not deliver its own pixels");
         if (s->accum.count < n) RT_HIP(s->accum.alloc(n));
         a.accum = s->accum.ptr;
         RT_HIP(hipMemsetAsync(s->segments.ptr, 0, rtdev::RT_STAT_SLOTS * sizeof(unsigned long long), stream));
@@ -399,8 +400,8 @@ int rtapi::enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderPara
         RT_HIP(hipEventRecord(s->ev_traced, stream));
         if (!delivery)
             RT_HIP((s->exact ? rtdev_launch_resolve_chunks_exact : rtdev_launch_resolve_chunks)(s->partial.ptr, out_device, p->width, p->height, chunks_done, a.strip_rows,
-                                               a.strip_count, a.strip_index, a.step_x, a.step_y, a.cover_w, a.cover_h, 0,
-                                               p->width, p->samples, stream));
+                                               a.strip_count, a.strip_index, a.step_x, a.step_y, a.cover_w, a.cover_h,
+                                               out_col_step, out_cols, p->samples, stream));
         RT_HIP(hipEventRecord(s->ev_resolved, stream));
         s->last_chunks = chunks_done;
     }

@@ -308,22 +308,34 @@ int deliver_tiles(RtScene *const *scenes, int n, const RtCamera *camera, const R
     return finish_shares(shares);
 }
 
-// The whole-frame path behind the tile stream where the delivering launch does not apply (preview scale, the v1
-// kernel, a tile grid wider than the image): the tiles are cut from the finished frame.  The v1 kernel is traced in
-// sample batches with a synchronisation after each, so that the hook is polled about as often as the reference
-// polls it per tile row (cpu.rs:55).
+// The two-pass path behind the tile stream where the delivering launch does not apply (preview scale, the v1 kernel, a
+// tile grid wider than the image): the tiles are cut from the finished frame.  The pooled kernel's resolve pass writes
+// the stream's tile-column layout itself (k_resolve_chunks_f64), ONE copy brings the frame into the scene's pinned
+// buffer and the callbacks read it in place — the reference's interactive mode renders a preview on every camera move
+// (interactive.rs:196-267), so what this path costs beyond the 0.5 ms of device work is the frame rate of the window
+// (1080p preview: 14.3 ms with a pageable frame, a zero-initialised staging vector and a host-side repack; now 2.x).
+// The v1 kernel is traced in sample batches with a synchronisation after each, so that the hook is polled about as
+// often as the reference polls it per tile row (cpu.rs:55), and its plain frame is repacked per column on the host.
 int tiles_from_frame(RtScene *s, const RtCamera *camera, const RtRenderParams *p, RtTileCallback callback, void *user,
                      const Cancel &cancel) {
     const size_t n = (size_t)p->width * (size_t)p->height * 3;
     if (s->frame.count < n) RT_HIP(s->frame.alloc(n));
+    int rc = ensure_host_frame(s, n);
+    if (rc != RT_OK) return rc;
     int batch = 0;
     if (cancel.armed() && s->use_v1) { // at most 32 launches, at least 16 samples each
         batch = (p->samples + 31) / 32;
         if (batch < 16) batch = 16;
         if (batch > p->samples) batch = p->samples;
     }
-    int rc = rtapi::enqueue_render(s, camera, p, s->frame.ptr, s->stream, batch, cancel);
-    if (rc == RT_OK) rc = rtapi::wait_event(s->ev_resolved, cancel);
+    const int width_step = p->width / p->tiles_w, height_step = p->height / p->tiles_h;
+    const bool column_layout = !s->use_v1 && width_step > 0 && p->tiles_w > 1; // written by the resolve pass itself
+    rc = rtapi::enqueue_render(s, camera, p, s->frame.ptr, s->stream, batch, cancel, nullptr, column_layout ? width_step : 0,
+                               column_layout ? p->tiles_w : 1);
+    if (rc == RT_OK) RT_HIP(hipMemcpyAsync(s->host_frame, s->frame.ptr, n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    hipEvent_t copied = s->ev_resolved; // re-recorded behind the copy: rt_scene_last_stats reads ev_traced -> ev_resolved (+ the copy)
+    if (rc == RT_OK) RT_HIP(hipEventRecord(copied, s->stream));
+    if (rc == RT_OK) rc = rtapi::wait_event(copied, cancel);
     if (rc == RT_ERR_CANCEL_EVENT) { // cpu.rs:55-62: return Ok, no tile written
         rc = s->use_v1 ? RT_OK : rtapi::poison_queue(s);
         (void)hipStreamSynchronize(s->stream);
@@ -334,22 +346,27 @@ int tiles_from_frame(RtScene *s, const RtCamera *camera, const RtRenderParams *p
         return rc;
     }
     RT_HIP(hipStreamSynchronize(s->stream));
-    std::vector<double> frame(n);
-    RT_HIP(hipMemcpy(frame.data(), s->frame.ptr, n * sizeof(double), hipMemcpyDeviceToHost));
-    const int width_step = p->width / p->tiles_w, height_step = p->height / p->tiles_h;
-    std::vector<double> column;
+    std::vector<double> column; // v1 / single-column grids: one column of the plain frame, repacked
     for (int ws = 0; ws < p->tiles_w; ++ws) {
         const int x = width_step * ws, w = ws == p->tiles_w - 1 ? p->width - x : width_step;
         if (w <= 0) continue;
-        column.resize((size_t)w * (size_t)p->height * 3);
-        for (int r = 0; r < p->height; ++r)
-            memcpy(&column[(size_t)r * w * 3], &frame[((size_t)r * p->width + x) * 3], (size_t)w * 3 * sizeof(double));
+        const double *col;
+        if (column_layout) {
+            col = s->host_frame + (size_t)p->height * (size_t)x * 3;
+        } else if (w == p->width) {
+            col = s->host_frame;
+        } else {
+            column.resize((size_t)w * (size_t)p->height * 3);
+            for (int r = 0; r < p->height; ++r)
+                memcpy(&column[(size_t)r * w * 3], s->host_frame + ((size_t)r * p->width + x) * 3, (size_t)w * 3 * sizeof(double));
+            col = column.data();
+        }
         for (int hs = 0; hs < p->tiles_h; ++hs) {
             if (cancel.raised()) return RT_OK;
             const int y = height_step * hs;
             const int h = hs == p->tiles_h - 1 ? p->height - y : height_step;
             if (h <= 0) continue;
-            callback(user, column.data() + (size_t)y * (size_t)w * 3, y, x, w, h);
+            callback(user, col + (size_t)y * (size_t)w * 3, y, x, w, h);
         }
     }
     return RT_OK;

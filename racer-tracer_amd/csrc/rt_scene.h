@@ -121,8 +121,11 @@ int check_params(const RtCamera *camera, const RtRenderParams *p);
 // Enqueue trace + resolve on `stream` (two-pass path: the resolve kernel writes out_device), or — with a Delivery —
 // ONE delivering launch that finishes its own pixels (out_device is ignored).  `cancel` is polled between the
 // sample batches of the v1 kernel only.  Returns RT_ERR_CANCEL_EVENT when cancelled (callers map that to RT_OK).
+// out_col_step / out_cols: layout the RESOLVE pass of the two-pass path writes (rt_trace_pool_kernel.hip:
+// k_resolve_chunks_f64): the plain frame, or the tile stream's column layout.
 int enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, double *out_device,
-                   hipStream_t stream, int batch, const Cancel &cancel, const Delivery *delivery = nullptr);
+                   hipStream_t stream, int batch, const Cancel &cancel, const Delivery *delivery = nullptr,
+                   int out_col_step = 0, int out_cols = 1);
 // Block until `ev` has happened, polling `cancel` meanwhile (RT_ERR_CANCEL_EVENT as soon as it is raised).
 int wait_event(hipEvent_t ev, const Cancel &cancel);
 // Ends the pool launches in flight on `s` early: every item counter becomes 2^31 (rt_api.hip).

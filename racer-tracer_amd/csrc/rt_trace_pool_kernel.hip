@@ -972,35 +972,37 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
 // vec3.rs:119-125 scale_sqrt over the owned rows: out = sqrt(sum over chunks / samples),
 // chunks added in index order.  With step_x/step_y > 1 (preview renderer) every pixel takes
 // the value of its block's top-left pixel and pixels outside the covered area are (0,0,0)
-// (cpu_scaled.rs:50-52, :80-89).
+// (cpu_scaled.rs:50-52, :80-89).  `out` is the plain [height][width][3] frame (out_cols == 1) or the tile-column layout
+// of the tile stream — column c of out_col_step pixels (the last takes the remainder, cpu.rs:97-109) stored as
+// [height][column width][3] behind the columns before it — so that a tile of rt_render is one contiguous run.
 __global__ __launch_bounds__(256) void k_resolve_chunks_f64(const double *__restrict__ partial, double *__restrict__ out,
                                                             int width, int height, int n_chunks, int strip_rows,
                                                             int strip_count, int strip_index, int step_x, int step_y,
-                                                            int cover_w, int cover_h, int x0, int x_count,
+                                                            int cover_w, int cover_h, int out_col_step, int out_cols,
                                                             double scale) {
     const size_t n = (size_t)width * (size_t)height * 3;
-    // a column window [x0, x0 + x_count) of a progressive render: the grid runs over the window only
-    const size_t n_work = x_count < width ? (size_t)x_count * (size_t)height * 3 : n;
-    for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_work; w += (size_t)gridDim.x * blockDim.x) {
-        size_t i = w;
-        if (x_count < width) {
-            const size_t row = w / ((size_t)x_count * 3);
-            i = (row * (size_t)width + (size_t)x0) * 3 + (w - row * (size_t)x_count * 3);
-        }
-        size_t src = i;
-        if (strip_count > 1 || step_x > 1 || step_y > 1) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        size_t src = i, dst = i;
+        if (strip_count > 1 || step_x > 1 || step_y > 1 || out_cols > 1) {
             const size_t pixel = i / 3;
             const int row = (int)(pixel / (size_t)width), col = (int)(pixel - (size_t)row * (size_t)width);
             if (strip_count > 1 && (row / strip_rows) % strip_count != strip_index) continue;
+            if (out_cols > 1) {
+                int c = col / out_col_step;
+                if (c > out_cols - 1) c = out_cols - 1;
+                const int col_x = c * out_col_step;
+                const int col_w = c == out_cols - 1 ? width - col_x : out_col_step;
+                dst = ((size_t)height * (size_t)col_x + (size_t)row * (size_t)col_w + (size_t)(col - col_x)) * 3 + (i - pixel * 3);
+            }
             if (col >= cover_w || row >= cover_h) {
-                out[i] = 0.0;
+                out[dst] = 0.0;
                 continue;
             }
             src = ((size_t)(row - row % step_y) * (size_t)width + (size_t)(col - col % step_x)) * 3 + (i - pixel * 3);
         }
         double acc = 0.0;
         for (int c = 0; c < n_chunks; ++c) acc += partial[(size_t)c * n + src];
-        out[i] = sqrt(scale * acc);
+        out[dst] = sqrt(scale * acc);
     }
 }
 
@@ -1056,19 +1058,19 @@ extern "C" hipError_t RT_LAUNCHER(rtdev_launch_trace_pool)(const rtdev::TraceArg
 }
 
 extern "C" hipError_t RT_LAUNCHER(rtdev_launch_resolve_chunks)(const double *partial, double *out, int width, int height, int n_chunks,
-                                                  int strip_rows, int strip_count, int strip_index, int step_x, int step_y,
-                                                  int cover_w, int cover_h, int x0, int x_count, int samples,
-                                                  hipStream_t stream) {
-    if (x_count <= 0 || x_count > width) {
-        x0 = 0;
-        x_count = width;
+                                                               int strip_rows, int strip_count, int strip_index, int step_x, int step_y,
+                                                               int cover_w, int cover_h, int out_col_step, int out_cols, int samples,
+                                                               hipStream_t stream) {
+    if (out_cols <= 1 || out_col_step <= 0) {
+        out_cols = 1;
+        out_col_step = width;
     }
-    size_t n = (size_t)x_count * (size_t)height * 3;
+    size_t n = (size_t)width * (size_t)height * 3;
     unsigned blocks = (unsigned)((n + 255) / 256);
     if (blocks > 4096u) blocks = 4096u;
     if (blocks == 0) return hipSuccess;
     hipLaunchKernelGGL(RT_KNS::k_resolve_chunks_f64, dim3(blocks), dim3(256), 0, stream, partial, out, width, height,
-                       n_chunks, strip_rows, strip_count, strip_index, step_x, step_y, cover_w, cover_h, x0, x_count,
+                       n_chunks, strip_rows, strip_count, strip_index, step_x, step_y, cover_w, cover_h, out_col_step, out_cols,
                        1.0 / (double)samples);
     return hipGetLastError();
 }
