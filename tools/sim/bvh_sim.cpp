@@ -166,6 +166,100 @@ int main(int argc, char **argv) {
         }
         return steps;
     };
+    // The skip-link walk as the sequence of phases a lane of the device's while-while loop goes through:
+    // (descent steps until a leaf is entered, primitives of that leaf) ... (descent steps until the tree is left, 0).
+    auto walk_trace = [&](const Ray &r, std::vector<std::pair<int, int>> &phases) {
+        double bt = INFINITY;
+        int i = 0, steps = 0;
+        phases.clear();
+        while (i < n) {
+            ++steps;
+            double tn;
+            if (hit_box(bvh.nodes[i], bvh.center, r, bt, tn)) {
+                const int fc = bvh.nodes[i].first_count;
+                if (fc & 7) {
+                    phases.push_back({steps, fc & 7});
+                    steps = 0;
+                    for (int k = 0; k < (fc & 7); ++k) {
+                        double t;
+                        if (hit_prim(d->primitives[bvh.prim_index[(fc >> 3) + k]], r, bt, t)) bt = t;
+                    }
+                }
+                i = i + 1;
+            } else {
+                i = bvh.nodes[i].skip;
+            }
+        }
+        phases.push_back({steps, 0});
+    };
+    // What would lanes that fetch a NEW ray when theirs is through buy?  A wave of 64 lanes in lockstep, while-while:
+    // a descent round costs `cd` (every lane that is not at a leaf takes one step), a leaf round `cl` per primitive (the
+    // wave runs max-count rounds).  keep_in_lanes: each lane owns one ray and the wave ends when its slowest ray does
+    // (the kernel today); refill: a lane whose ray is through takes the next ray of the queue at the next loop top
+    // (a wavefront walk over rays that wait in memory), `cf` per loop top at which somebody fetches.
+    // straggle: the descent rounds of an outer round stop once no more than this many lanes are still descending (they go on
+    // in the next outer round while the others test their leaves); 0 = every lane reaches its leaf first (the kernel today)
+    auto wave_cost = [&](const std::vector<std::vector<std::pair<int, int>>> &traces, bool refill, double cd, double cl, double cf,
+                         double &lane_use, int straggle = 0) {
+        struct Lane { int ray = -1; size_t phase = 0; int left = 0; };
+        std::vector<Lane> lanes(64);
+        size_t next = 0;
+        double cost = 0, useful = 0;
+        auto assign = [&](Lane &L) {
+            L.ray = (int)next++;
+            L.phase = 0;
+            L.left = traces[(size_t)L.ray][0].first;
+        };
+        while (true) {
+            bool fetched = false, any = false;
+            for (Lane &L : lanes) {
+                if (L.ray < 0 && next < traces.size() && (refill || std::all_of(lanes.begin(), lanes.end(), [](const Lane &x) { return x.ray < 0; }))) {
+                    // without refill a new group of 64 starts only when the whole wave is idle
+                }
+            }
+            const bool all_idle = std::all_of(lanes.begin(), lanes.end(), [](const Lane &x) { return x.ray < 0; });
+            for (Lane &L : lanes)
+                if (L.ray < 0 && next < traces.size() && (refill || all_idle)) { assign(L); fetched = true; }
+            for (const Lane &L : lanes) any = any || L.ray >= 0;
+            if (!any) break;
+            if (fetched && refill) cost += cf;
+            // descent rounds until every lane with a ray stands at a leaf (or has left the tree)
+            while (true) {
+                int walking = 0;
+                for (const Lane &L : lanes) walking += L.ray >= 0 && L.left > 0;
+                if (walking == 0 || (walking <= straggle && walking < 64)) {
+                    int at_leaf = 0;
+                    for (const Lane &L : lanes) at_leaf += L.ray >= 0 && L.left == 0;
+                    if (walking == 0 || at_leaf > 0) break;
+                }
+                for (Lane &L : lanes)
+                    if (L.ray >= 0 && L.left > 0) --L.left;
+                cost += cd;
+                useful += cd * walking / 64.0;
+            }
+            // leaf rounds (lanes still descending sit them out)
+            int rounds = 0;
+            double lane_rounds = 0;
+            for (Lane &L : lanes)
+                if (L.ray >= 0 && L.left == 0) {
+                    const int c = traces[(size_t)L.ray][L.phase].second;
+                    rounds = std::max(rounds, c);
+                    lane_rounds += c;
+                }
+            cost += cl * rounds;
+            useful += cl * lane_rounds / 64.0;
+            for (Lane &L : lanes)
+                if (L.ray >= 0 && L.left == 0) {
+                    const auto &tr = traces[(size_t)L.ray];
+                    if (tr[L.phase].second == 0) { L.ray = -1; continue; } // left the tree
+                    ++L.phase;
+                    L.left = tr[L.phase].first;
+                    if (L.left == 0 && tr[L.phase].second == 0) L.ray = -1;
+                }
+        }
+        lane_use = useful / cost;
+        return cost / (double)traces.size();
+    };
     // (c) skip links, two nodes per step: node i and its layout successor i + 1 are fetched and tested together; when
     //     the walk goes on at i + 1 anyway (i is a hit inner node, or a missed node whose skip link is i + 1) the
     //     second result is used at once.  No stack, no new layout.
@@ -315,6 +409,22 @@ int main(int argc, char **argv) {
         printf("bounce %d: %zu rays | skip-link: %.1f boxes %.1f prims per ray, %.1f steps per wave | ordered+stack: %.1f boxes %.1f prims per ray, "
                "%.1f steps per wave (2 boxes each), stack depth %d | skip-link, two per step: %.1f boxes, %.1f steps per wave | closest hits differ: %ld\n",
                bounce, rays.size(), a.boxes / nr, a.prims / nr, wave_a / nw, b.boxes / nr, b.prims / nr, wave_b / nw, max_sp, c2.boxes / nr, wave_c / nw, mismatches);
+        { // lockstep model of a wave over this bounce's rays: today's walk against one whose lanes fetch new rays
+            std::vector<std::vector<std::pair<int, int>>> traces(rays.size());
+            for (size_t j = 0; j < rays.size(); ++j) walk_trace(rays[j], traces[j]);
+            // costs in SIMD cycles per wave: a descent step is ~24 32-bit vector instructions, a leaf primitive ~40 f64 ones
+            const double cd = 24 * 2.3, cl = 40 * 4.2, cf = 60 * 2.3;
+            double use_a = 0, use_b = 0;
+            const double a1 = wave_cost(traces, false, cd, cl, cf, use_a), b1 = wave_cost(traces, true, cd, cl, cf, use_b);
+            printf("bounce %d, wave model: rays kept in lanes %.0f cycles per ray (%.0f %% of lane-cycles useful) | lanes refilled from a queue %.0f (%.0f %%) | x %.2f\n",
+                   bounce, a1, 100 * use_a, b1, 100 * use_b, a1 / b1);
+            for (int straggle : {8, 16, 32}) {
+                double ua = 0, ub = 0;
+                const double a2 = wave_cost(traces, false, cd, cl, cf, ua, straggle), b2 = wave_cost(traces, true, cd, cl, cf, ub, straggle);
+                printf("bounce %d, wave model, leaves tested once <= %d lanes still descend: kept in lanes %.0f (%.0f %%) | refilled %.0f (%.0f %%)\n",
+                       bounce, straggle, a2, 100 * ua, b2, 100 * ub);
+            }
+        }
         rays.swap(next);
     }
     rth_session_close(session);
