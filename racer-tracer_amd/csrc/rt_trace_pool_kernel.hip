@@ -762,11 +762,16 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                                 }
                                 if (i < end) test_plane(axis, load_prim_uniform(A.prims, i), i);
                             };
-                            group(std::integral_constant<int, 2>(), 0, A.rect_end[0]);              // XY
-                            group(std::integral_constant<int, 1>(), A.rect_end[0], A.rect_end[1]);  // XZ
-                            group(std::integral_constant<int, 0>(), A.rect_end[1], A.rect_end[2]);  // YZ
+                            // the group bounds are re-read from the kernel arguments HERE (kernargs_here): hoisted out of the
+                            // path loop their emptiness tests sit in SGPR pairs that the allocator parks in VGPR lanes, and
+                            // every iteration pays a v_readlane (4.3 SIMD cycles of the saturated vector pipe) per half of them
+                            const RT_CONSTANT TraceArgs *KB = kernargs_here();
+                            const int end_xy = KB->rect_end[0], end_xz = KB->rect_end[1], end_yz = KB->rect_end[2];
+                            group(std::integral_constant<int, 2>(), 0, end_xy);       // XY
+                            group(std::integral_constant<int, 1>(), end_xy, end_xz);  // XZ
+                            group(std::integral_constant<int, 0>(), end_xz, end_yz);  // YZ
                             if (PRIMS == PRIMS_ANY) {
-                                int i = A.rect_end[2];
+                                int i = end_yz;
                                 for (; i < A.sphere_end; ++i) { // plain spheres: sphere.rs:39-59, no switch, no wrapper
                                     double t;
                                     int aux;
