@@ -241,3 +241,30 @@ def test_paths_that_do_not_deliver_still_stream_tiles(rt, gpu):
     finally:
         v1.close()
         pool.close()
+
+
+@pytest.mark.parametrize("rows,count", [(5, 3), (12, 2), (3, 4)])
+def test_delivery_with_strips_that_cut_item_tiles(rt, gpu, rows, count):
+    """Strip heights that are not a multiple of 8 regroup the pixels that share an item tile (rt_abi.h): the frame then
+    agrees with the whole-frame render to rounding only — but the delivering launch and the two-pass path still see the
+    same tiles, so THEY must agree bit for bit, share by share (deliver_item's per-lane row mapping)."""
+    import torch
+    bundle, cam, _ = S.cornell_box_boxes()
+    w, h, spp = 150, 83, 20
+    camera = S.camera_for(cam, w, h)
+    scene = rt.Scene(bundle)
+    try:
+        whole = two_pass_frame(scene, camera, S.abi.render_params(w, h, spp))
+        for idx in range(count):
+            p = S.abi.render_params(w, h, spp, strip_rows=rows, strip_count=count, strip_index=idx)
+            dev = torch.full((h, w, 3), -1.0, dtype=torch.float64, device="cuda")
+            scene.render_frame_device(camera, p, dev.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            want = dev.cpu().numpy()
+            got = scene.render_frame(camera, p)
+            own = ((np.arange(h) // rows) % count) == idx
+            assert np.array_equal(got[own], want[own])
+            assert (got[~own] == 0).all() and (want[~own] == -1).all()
+            assert np.abs(got[own] - whole[own]).max() < 1e-12
+    finally:
+        scene.close()
