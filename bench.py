@@ -501,6 +501,8 @@ def main():
         t_host = time.time()
         if world == 1 and dist is None and not args.no_host_delivery:
             out["host_delivered"] = host_delivery(rt, scene, session)
+            # the reference's own boundary (10x10 tile stream into host memory) as one number next to `value`
+            out["value_host_delivered"] = out["host_delivered"]["rt_render"]["value"]
             out["host_delivered"]["vs_device_resident"] = {
                 k: round(out["host_delivered"][k]["ms"] / ms_per_step, 4) for k in ("rt_render", "rt_render_frame")}
         t_host = time.time() - t_host
