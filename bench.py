@@ -193,7 +193,7 @@ def live_pmc_summary(args):
         return None, "rocprofv3 is not on PATH"
     child = ["--workload", args.workload] + (["--spp", str(args.spp)] if args.spp else [])
     t0 = time.time()
-    summary = pmc.collect(child, log=lambda m: sys.stderr.write("bench.py: %s\n" % m))
+    summary = pmc.collect(child, log=lambda m: sys.stderr.write("bench.py: %s\n" % m), budget_s=150, pass_timeout=60)
     summary["_stamp"]["collected_in_s"] = round(time.time() - t0, 1)
     return summary, None
 

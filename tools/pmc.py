@@ -85,15 +85,26 @@ def run_pass(counters, bench_args, keep_dir=None, timeout=240):
     return agg, bench, err
 
 
-def collect(bench_args, groups=None, keep_dir=None, log=None):
-    """All passes -> summary dict (the format of profiles/rNN_<workload>_pmc_summary.json)."""
+def collect(bench_args, groups=None, keep_dir=None, log=None, budget_s=None, pass_timeout=240):
+    """All passes -> summary dict (the format of profiles/rNN_<workload>_pmc_summary.json).
+    budget_s: stop starting passes once this much wall time has gone (bench.py's live collection must not turn a
+    misbehaving profiler into a bench run of half an hour)."""
+    import time
+    t_begin = time.time()
     names = list(groups or STANDARD)
     summary = {"_stamp": {"source_sha": kernel_source_sha(), "bench_args": " ".join(bench_args), "kernel_ms_under_pmc": [],
                           "groups": {}, "errors": []}}
     stamp = summary["_stamp"]
     for name in names:
         counters = GROUPS.get(name, name)
-        agg, bench, err = run_pass(counters, bench_args, os.path.join(keep_dir, name.replace(" ", "_")) if keep_dir else None)
+        timeout = pass_timeout
+        if budget_s is not None:
+            left = budget_s - (time.time() - t_begin)
+            if left < 20:
+                stamp["errors"].append("%s: skipped, the %d s budget of the live collection is spent" % (name, budget_s))
+                continue
+            timeout = min(timeout, left)
+        agg, bench, err = run_pass(counters, bench_args, os.path.join(keep_dir, name.replace(" ", "_")) if keep_dir else None, timeout=timeout)
         if log:
             log("pmc pass %-6s %s" % (name, "ok" if err is None else err))
         if err is not None:
