@@ -243,6 +243,8 @@ def valu_roofline(c, kernel_ms, segments):
     out.update({"achieved": round(achieved, 3), "peak": F64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / F64_VECTOR_PEAK_TFLOPS, 4),
                 "issue_frac": round(issue_cycles / simd_cycles, 4),
+                # ... of which the share spent on lanes that were enabled (the rest ran masked off: divergence)
+                "useful_lane_issue_frac": round(issue_cycles / simd_cycles * lanes / 64.0, 4),
                 "f64_flop_per_segment": round(flops / segments, 2),
                 "valu_insts_by_class": {k: round(v / total, 4) for k, v in classes.items()},
                 "issue_cost_cycles": ISSUE_COST})
