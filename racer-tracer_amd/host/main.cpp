@@ -80,12 +80,12 @@ int main(int argc, char **argv) {
     ScreenBuffer sb{session, params.width, params.height, std::vector<double>((size_t)params.width * (size_t)params.height * 3, 0.0)};
     fprintf(stderr, "Rendering image...\n"); // interactive.rs:229
     auto t0 = std::chrono::steady_clock::now();
+    // the reference's tile stream (cpu.rs:64-70): every finished tile goes through ScreenBuffer::update's tone map;
+    // with several devices a tile column arrives once every device has finished its strips of it
     if (scenes.size() == 1) {
         rc = rt_render(scenes[0], rth_session_camera(session), &params, on_tile, &sb, nullptr);
-    } else { // the whole frame as ONE BufferUpdate (renderer/image.rs:56-62), strips gathered from all devices
-        std::vector<double> frame(sb.buffer.size());
-        rc = rt_render_frame_multi(scenes.data(), (int)scenes.size(), rth_session_camera(session), &params, 0, frame.data());
-        if (rc == RT_OK) on_tile(&sb, frame.data(), 0, 0, params.width, params.height);
+    } else {
+        rc = rt_render_multi(scenes.data(), (int)scenes.size(), rth_session_camera(session), &params, 0, on_tile, &sb, nullptr, nullptr);
     }
     double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (rc != RT_OK) {
