@@ -169,7 +169,7 @@ int deliver_frame(RtScene *const *scenes, int n, const RtCamera *camera, const R
         // thousands of resident waves — so a small last band costs an unbalanced tail of about one item's duration,
         // while a large one costs the copy of its rows after the GPU is done.  Items are short when a frame has many
         // chunks (C3: 19 chunks, 0.2 ms items: 32 bands, +0.8 ms in all) and long when it has few (64 spp of a
-        // 485-sphere scene: 4 chunks, 1.6 ms items: 32 bands cost +3.5 ms, 8 bands +1.x): two bands per chunk.
+        // 485-sphere scene: 4 chunks, 1.6 ms items: 32 bands cost +3.5 ms, 8 bands +0.7): two bands per chunk.
         int bands = tile_rows / 2; // at least two tile rows each
         const int by_chunks = 2 * rtapi::chunk_count(sh.params.samples);
         if (bands > by_chunks) bands = by_chunks < 4 ? 4 : by_chunks;
@@ -313,7 +313,7 @@ int deliver_tiles(RtScene *const *scenes, int n, const RtCamera *camera, const R
 // the stream's tile-column layout itself (k_resolve_chunks_f64), ONE copy brings the frame into the scene's pinned
 // buffer and the callbacks read it in place — the reference's interactive mode renders a preview on every camera move
 // (interactive.rs:196-267), so what this path costs beyond the 0.5 ms of device work is the frame rate of the window
-// (1080p preview: 14.3 ms with a pageable frame, a zero-initialised staging vector and a host-side repack; now 2.x).
+// (1080p preview: 14.3 ms with a pageable frame, a zero-initialised staging vector and a host-side repack; now 1.44).
 // The v1 kernel is traced in sample batches with a synchronisation after each, so that the hook is polled about as
 // often as the reference polls it per tile row (cpu.rs:55), and its plain frame is repacked per column on the host.
 int tiles_from_frame(RtScene *s, const RtCamera *camera, const RtRenderParams *p, RtTileCallback callback, void *user,
