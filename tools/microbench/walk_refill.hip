@@ -1,0 +1,308 @@
+// walk_refill.hip — what would lanes that fetch a NEW ray when theirs is through buy the BVH walk?
+//
+// The BVH variants of the trace kernel are issue-bound at ~21 of 64 lanes per vector instruction: a wave's lanes each
+// own one path and the walk runs until the wave's slowest ray is through.  tools/sim/bvh_sim.cpp MODELS
+// a walk whose lanes are refilled from a ray queue (a wavefront tracer's trace kernel) at 1.4 - 1.6 x on bounce rays.
+// This MEASURES it: the same skip-link walk (rt_bvh_slab.h's f32 culling boxes in LDS, f64 sphere tests, while-while)
+// over the `random` scene's own bounce rays, once with 64 rays pinned to the 64 lanes of a wave until all are through
+// (mode 0, the kernel today), once with every lane fetching the next ray of a global queue as soon as its own is
+// through (mode 1), optionally testing leaves as soon as few lanes still descend (mode 2).
+// Nothing here is product code; it answers whether a wavefront redesign of the BVH variants would pay.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Iracer-tracer_amd -o build/walk_refill tools/microbench/walk_refill.hip \
+//         racer-tracer_amd/build/product/rt_bvh.o -Lracer-tracer_amd/lib -lracer_tracer_amd -Wl,-rpath,$PWD/racer-tracer_amd/lib
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+#include "rt_abi.h"
+#include "rt_host.h"
+#include "csrc/rt_bvh.h"
+#include "csrc/rt_bvh_slab.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+struct Ray { double o[3], d[3], time, pad; };                 // 64 B
+struct Sphere { double c0[3], r2, dc[3], inv_dt_unused; };    // 64 B: centre at time t = c0 + t * dc (time interval [0, 1])
+struct Hit { double t; int prim, pad; };
+
+struct Args {
+    const rtdev::BvhNode *nodes;
+    const Sphere *spheres; // in leaf order
+    const Ray *rays;
+    Hit *hits;
+    unsigned int *queue;
+    int n_nodes, n_rays, mode, straggle, fetch_min;
+    double root_mn[3], root_mx[3], center[3];
+};
+
+__device__ __forceinline__ int lane_rank(uint64_t mask) {
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__global__ __launch_bounds__(256, 4) void k_walk(const Args A) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    rtdev::BvhNode *nodes = reinterpret_cast<rtdev::BvhNode *>(lds);
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(A.nodes);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds);
+        for (int i = threadIdx.x; i < A.n_nodes * 2; i += 256) dst[i] = src[i];
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const int n = A.n_nodes;
+    // per-lane ray state
+    int ray = -1, i = n, best = -1;
+    double ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, time = 0, inv_a = 0, best_t = 0, t0 = 0;
+    rtdev::SlabRay sr = {};
+    float tmin_f = 0.f, best_f = 0.f;
+    const float slack = 0x1p-20f;
+    bool queue_dry = false;
+    unsigned guard = 0; // every wave leaves after a bounded number of rounds whatever happens
+    for (;;) {
+        // ---- hand out rays
+        const bool idle = ray < 0;
+        const uint64_t idle_mask = __ballot(idle);
+        const int n_idle = __popcll(idle_mask);
+        // a fetch is a round trip to a global counter and a 64-byte load per lane: refilling lanes one by one makes the walk
+        // wait for memory every round (measured: 2.4 x SLOWER than pinned rays), so lanes are refilled fetch_min at a time
+        const bool fetch = !queue_dry && (A.mode == 0 ? n_idle == 64 : (n_idle >= A.fetch_min || n_idle == 64));
+        if (fetch) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(A.queue, (unsigned)n_idle);
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            if (base + (unsigned)n_idle >= (unsigned)A.n_rays) queue_dry = true;
+            const unsigned mine = base + (unsigned)lane_rank(idle_mask);
+            if (idle && mine < (unsigned)A.n_rays) {
+                ray = (int)mine;
+                const Ray R = A.rays[mine];
+                ox = R.o[0]; oy = R.o[1]; oz = R.o[2];
+                dx = R.d[0]; dy = R.d[1]; dz = R.d[2];
+                time = R.time;
+                inv_a = 1.0 / (dx * dx + dy * dy + dz * dz);
+                best_t = __builtin_inf();
+                best = -1;
+                i = 0;
+                // closest_hit_bvh's prologue: clip to the root box in f64, then f32 around the root's centre
+                const double ix = 1.0 / dx, iy = 1.0 / dy, iz = 1.0 / dz;
+                const double ax = (A.root_mn[0] - ox) * ix, bx = (A.root_mx[0] - ox) * ix;
+                const double ay = (A.root_mn[1] - oy) * iy, by = (A.root_mx[1] - oy) * iy;
+                const double az = (A.root_mn[2] - oz) * iz, bz = (A.root_mx[2] - oz) * iz;
+                const double t_enter = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
+                const double t_exit = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
+                if (!(fmax(t_enter, 0.001) <= t_exit)) i = n; // misses the scene
+                t0 = t_enter > 0.0 ? t_enter : 0.0;
+                sr = rtdev::slab_ray((float)(fma(t0, dx, ox) - A.center[0]), (float)(fma(t0, dy, oy) - A.center[1]),
+                                     (float)(fma(t0, dz, oz) - A.center[2]), ix, iy, iz);
+                tmin_f = (float)(0.001 - t0) - fabsf((float)(0.001 - t0)) * slack - 0x1p-126f;
+                best_f = __builtin_inff();
+            }
+        }
+        if (__ballot(ray >= 0) == 0) break; // queue dry and nothing in flight
+        if (++guard > (1u << 22)) break;
+        // ---- descent: until every lane with a ray stands at a leaf or has left the tree (or few still descend)
+        int count = 0, first = 0;
+        for (;;) {
+            const bool walking = ray >= 0 && i < n && count == 0;
+            const int n_walking = __popcll(__ballot(walking));
+            if (n_walking == 0) break;
+            if (A.mode == 2 && n_walking <= A.straggle && __ballot(ray >= 0 && count > 0) != 0) break;
+            if (walking) {
+                const uint4 *raw = reinterpret_cast<const uint4 *>(&nodes[i]);
+                const uint4 q0 = raw[0], q1 = raw[1];
+                const float mn[3] = {__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)};
+                const float mx[3] = {__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)};
+                const int skip = (int)q1.z, fc = (int)q1.w;
+                const bool hit = rtdev::slab_hit(mn, mx, sr, tmin_f, best_f, slack);
+                i = hit ? i + 1 : skip;
+                count = hit ? (fc & 7) : 0;
+                first = fc >> 3;
+            }
+        }
+        // ---- leaves
+        for (int k = 0; __ballot(ray >= 0 && k < count) != 0; ++k) {
+            if (ray >= 0 && k < count) {
+                const Sphere S = A.spheres[first + k];
+                const double cx = S.c0[0] + time * S.dc[0], cy = S.c0[1] + time * S.dc[1], cz = S.c0[2] + time * S.dc[2];
+                const double px = ox - cx, py = oy - cy, pz = oz - cz;
+                const double a = dx * dx + dy * dy + dz * dz;
+                const double hb = px * dx + py * dy + pz * dz;
+                const double c = px * px + py * py + pz * pz - S.r2;
+                const double disc = hb * hb - a * c;
+                if (disc >= 0.0) {
+                    const double sq = sqrt(disc);
+                    double root = (-hb - sq) * inv_a;
+                    if (root < 0.001 || best_t < root) root = (-hb + sq) * inv_a;
+                    if (!(root < 0.001 || best_t < root)) {
+                        best_t = root;
+                        best = first + k;
+                        const float f = (float)(best_t - t0);
+                        best_f = f + fabsf(f) * slack;
+                    }
+                }
+            }
+        }
+        // ---- rays that have left the tree are done
+        if (ray >= 0 && i >= n && count == 0) {
+            A.hits[ray] = Hit{best_t, best, 0};
+            ray = -1;
+        }
+        // (a lane that broke out of the descent at a leaf has count > 0 handled above and goes on descending next round)
+    }
+}
+
+struct HostScene {
+    std::vector<Sphere> spheres; // leaf order
+    rtdev::BvhBuild bvh;
+};
+
+static bool hit_sphere(const Sphere &s, const Ray &r, double tmax, double &t) {
+    const double c[3] = {s.c0[0] + r.time * s.dc[0], s.c0[1] + r.time * s.dc[1], s.c0[2] + r.time * s.dc[2]};
+    const double p[3] = {r.o[0] - c[0], r.o[1] - c[1], r.o[2] - c[2]};
+    const double a = r.d[0] * r.d[0] + r.d[1] * r.d[1] + r.d[2] * r.d[2];
+    const double hb = p[0] * r.d[0] + p[1] * r.d[1] + p[2] * r.d[2];
+    const double cc = p[0] * p[0] + p[1] * p[1] + p[2] * p[2] - s.r2;
+    const double disc = hb * hb - a * cc;
+    if (disc < 0) return false;
+    const double sq = std::sqrt(disc);
+    double root = (-hb - sq) / a;
+    if (root < 0.001 || root > tmax) {
+        root = (-hb + sq) / a;
+        if (root < 0.001 || root > tmax) return false;
+    }
+    t = root;
+    return true;
+}
+
+int main(int argc, char **argv) {
+    RthSession *session = nullptr;
+    if (rth_session_open("scenes/config_c2.yml", "random", nullptr, 1, &session) != RT_OK) {
+        printf("%s\n", rth_last_error_message());
+        return 1;
+    }
+    const RtSceneDesc *d = rth_session_scene(session);
+    const RtCamera *cam = rth_session_camera(session);
+    HostScene hs;
+    hs.bvh = rtdev::build_bvh(d->primitives, d->n_primitives, 3);
+    for (int pi : hs.bvh.prim_index) {
+        const RtPrimitive &p = d->primitives[pi];
+        Sphere s = {};
+        for (int k = 0; k < 3; ++k) {
+            s.c0[k] = p.p[k];
+            s.dc[k] = p.kind == RT_PRIM_MOVING_SPHERE ? p.center_b[k] - p.p[k] : 0.0;
+        }
+        s.r2 = p.p[3] * p.p[3];
+        hs.spheres.push_back(s);
+    }
+    // rays: primary rays of the scene's camera, then one diffuse bounce off whatever they hit (like bvh_sim)
+    const int W = 960, H = 540;
+    std::mt19937_64 rng(7);
+    std::uniform_real_distribution<double> U(0.0, 1.0);
+    std::vector<Ray> primary, bounce;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            Ray r = {};
+            const double u = (x + U(rng)) / (W - 1), v = (y + U(rng)) / (H - 1);
+            for (int k = 0; k < 3; ++k) {
+                r.o[k] = cam->origin[k];
+                r.d[k] = cam->upper_left_corner[k] + u * cam->horizontal[k] - v * cam->vertical[k] - cam->origin[k];
+            }
+            r.time = U(rng);
+            primary.push_back(r);
+        }
+    for (const Ray &r : primary) {
+        double bt = INFINITY;
+        int best = -1;
+        for (size_t i = 0; i < hs.spheres.size(); ++i) {
+            double t;
+            if (hit_sphere(hs.spheres[i], r, bt, t)) { bt = t; best = (int)i; }
+        }
+        if (best < 0) continue;
+        const Sphere &s = hs.spheres[(size_t)best];
+        Ray b = {};
+        double nrm[3], v[3], len;
+        for (int k = 0; k < 3; ++k) {
+            b.o[k] = r.o[k] + bt * r.d[k];
+            nrm[k] = (b.o[k] - (s.c0[k] + r.time * s.dc[k])) / std::sqrt(s.r2);
+        }
+        do {
+            len = 0;
+            for (int k = 0; k < 3; ++k) { v[k] = 2 * U(rng) - 1; len += v[k] * v[k]; }
+        } while (len >= 1 || len == 0);
+        for (int k = 0; k < 3; ++k) b.d[k] = nrm[k] + v[k] / std::sqrt(len);
+        b.time = r.time;
+        bounce.push_back(b);
+    }
+    printf("random scene: %d spheres, %zu nodes; %zu primary rays, %zu bounce rays\n", d->n_primitives, hs.bvh.nodes.size(), primary.size(), bounce.size());
+
+    Args a = {};
+    rtdev::BvhNode *d_nodes;
+    Sphere *d_spheres;
+    CK(hipMalloc((void **)&d_nodes, hs.bvh.nodes.size() * sizeof(rtdev::BvhNode)));
+    CK(hipMemcpy(d_nodes, hs.bvh.nodes.data(), hs.bvh.nodes.size() * sizeof(rtdev::BvhNode), hipMemcpyHostToDevice));
+    CK(hipMalloc((void **)&d_spheres, hs.spheres.size() * sizeof(Sphere)));
+    CK(hipMemcpy(d_spheres, hs.spheres.data(), hs.spheres.size() * sizeof(Sphere), hipMemcpyHostToDevice));
+    CK(hipMalloc((void **)&a.queue, sizeof(unsigned)));
+    a.nodes = d_nodes;
+    a.spheres = d_spheres;
+    a.n_nodes = (int)hs.bvh.nodes.size();
+    for (int k = 0; k < 3; ++k) { a.root_mn[k] = hs.bvh.root_mn[k]; a.root_mx[k] = hs.bvh.root_mx[k]; a.center[k] = hs.bvh.center[k]; }
+    const size_t lds = hs.bvh.nodes.size() * sizeof(rtdev::BvhNode);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int set = 0; set < 2; ++set) {
+        std::vector<Ray> rays = set == 0 ? primary : bounce;
+        const size_t base_n = rays.size();
+        while (rays.size() < 4000000) rays.insert(rays.end(), rays.begin(), rays.begin() + (long)base_n); // a few million rays
+        Ray *d_rays;
+        Hit *d_hits;
+        CK(hipMalloc((void **)&d_rays, rays.size() * sizeof(Ray)));
+        CK(hipMemcpy(d_rays, rays.data(), rays.size() * sizeof(Ray), hipMemcpyHostToDevice));
+        CK(hipMalloc((void **)&d_hits, rays.size() * sizeof(Hit)));
+        a.rays = d_rays;
+        a.hits = d_hits;
+        a.n_rays = (int)rays.size();
+        std::vector<Hit> ref;
+        struct Case { int mode, straggle, fetch_min; const char *name; };
+        const Case cases[] = {{0, 0, 64, "64 rays pinned to a wave's lanes (today)"},
+                              {1, 0, 1, "lanes refilled one by one"},
+                              {1, 0, 8, "refilled once 8 lanes are idle"},
+                              {1, 0, 16, "refilled once 16 lanes are idle"},
+                              {1, 0, 32, "refilled once 32 lanes are idle"},
+                              {2, 8, 16, "16 idle; leaves once <= 8 lanes descend"},
+                              {2, 16, 16, "16 idle; leaves once <= 16 lanes descend"}};
+        for (const Case &c : cases) {
+            a.mode = c.mode;
+            a.straggle = c.straggle;
+            a.fetch_min = c.fetch_min;
+            float best_ms = 1e30f;
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipMemset(a.queue, 0, sizeof(unsigned)));
+                CK(hipMemset(d_hits, 0xff, rays.size() * sizeof(Hit)));
+                CK(hipEventRecord(e0));
+                hipLaunchKernelGGL(k_walk, dim3(256 * 4), dim3(256), lds, 0, a);
+                CK(hipGetLastError());
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                best_ms = std::min(best_ms, ms);
+            }
+            std::vector<Hit> got(rays.size());
+            CK(hipMemcpy(got.data(), d_hits, rays.size() * sizeof(Hit), hipMemcpyDeviceToHost));
+            long differ = 0;
+            if (c.mode == 0) ref = got;
+            else for (size_t k = 0; k < got.size(); ++k) differ += got[k].prim != ref[k].prim || got[k].t != ref[k].t;
+            printf("%-8s rays | %-44s %7.2f ms  %6.2f G rays/s%s\n", set == 0 ? "primary" : "bounce", c.name, best_ms,
+                   rays.size() / best_ms / 1e6, c.mode == 0 ? "" : (differ ? "  RESULTS DIFFER" : "  same hits"));
+        }
+        CK(hipFree(d_rays));
+        CK(hipFree(d_hits));
+    }
+    rth_session_close(session);
+    return 0;
+}
