@@ -9,7 +9,7 @@
 // through (mode 1), optionally testing leaves as soon as few lanes still descend (mode 2).
 // Nothing here is product code; it answers whether a wavefront redesign of the BVH variants would pay.
 //
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Iracer-tracer_amd -o build/walk_refill tools/microbench/walk_refill.hip \
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -Iinclude -Iracer-tracer_amd -o build/walk_refill tools/microbench/walk_refill.hip \
 //         racer-tracer_amd/build/product/rt_bvh.o -Lracer-tracer_amd/lib -lracer_tracer_amd -Wl,-rpath,$PWD/racer-tracer_amd/lib
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -35,7 +35,9 @@ struct Args {
     const Ray *rays;
     Hit *hits;
     unsigned int *queue;
+    unsigned long long *stats; // [4] wave-level counts: rounds, descent iterations, leaf iterations, prologues
     int n_nodes, n_rays, mode, straggle, fetch_min;
+    int own_range; // 1: every wave takes rays from its OWN contiguous share (a counter in a register, no atomic at all)
     double root_mn[3], root_mx[3], center[3];
 };
 
@@ -43,7 +45,14 @@ __device__ __forceinline__ int lane_rank(uint64_t mask) {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-__global__ __launch_bounds__(256, 4) void k_walk(const Args A) {
+// 1/x like the trace kernel forms it (rt_trace_common.h: rcp_f64): hardware seed + one third-order step + fix-up
+__device__ __forceinline__ double rcp_fast(double x) {
+    const double r0 = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r0, 1.0);
+    return __builtin_amdgcn_div_fixup(fma(r0, fma(e, e, e), r0), x, 1.0);
+}
+
+template <bool PREFETCH> __global__ __launch_bounds__(256, 4) void k_walk(const Args A) {
     extern __shared__ __align__(16) unsigned char lds[];
     rtdev::BvhNode *nodes = reinterpret_cast<rtdev::BvhNode *>(lds);
     {
@@ -61,8 +70,89 @@ __global__ __launch_bounds__(256, 4) void k_walk(const Args A) {
     float tmin_f = 0.f, best_f = 0.f;
     const float slack = 0x1p-20f;
     bool queue_dry = false;
+    // mode 3: the prefetched next ray of this lane, and the request for indices that is in flight
+    int next_index = -1;
+    Ray next_ray = {};
+    bool asked = false, want = false;
+    unsigned asked_base = 0, asked_count = 0, want_rank = 0;
+    unsigned n_rounds = 0, n_descents = 0, n_leaves = 0, n_starts = 0; // wave-uniform: what the SIMD issues, whatever the lanes
+    // where the next rays come from: the global queue (one device-scope atomic per fetch, all waves on ONE address), or the
+    // wave's own share of the ray array
+    const unsigned n_waves = gridDim.x * (blockDim.x >> 6), wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const unsigned share = ((unsigned)A.n_rays + n_waves - 1) / n_waves;
+    unsigned own_next = wave * share;
+    const unsigned own_end = min(own_next + share, (unsigned)A.n_rays);
+    auto take = [&](unsigned count) -> unsigned { // first index of `count` rays; indices >= the returned limit do not exist
+        if (A.own_range) {
+            const unsigned base = own_next;
+            own_next += count;
+            return base;
+        }
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(A.queue, count);
+        return base; // lane 0's value; read with readfirstlane where it is used
+    };
+    const unsigned limit = A.own_range ? own_end : (unsigned)A.n_rays;
     unsigned guard = 0; // every wave leaves after a bounded number of rounds whatever happens
     for (;;) {
+        auto start = [&](int index, const Ray &R) { // closest_hit_bvh's prologue for a fresh ray
+            ray = index;
+            ox = R.o[0]; oy = R.o[1]; oz = R.o[2];
+            dx = R.d[0]; dy = R.d[1]; dz = R.d[2];
+            time = R.time;
+            inv_a = rcp_fast(dx * dx + dy * dy + dz * dz);
+            best_t = __builtin_inf();
+            best = -1;
+            i = 0;
+            // clip to the root box in f64, then f32 around the root's centre
+            const double ix = rcp_fast(dx), iy = rcp_fast(dy), iz = rcp_fast(dz);
+            const double ax = (A.root_mn[0] - ox) * ix, bx = (A.root_mx[0] - ox) * ix;
+            const double ay = (A.root_mn[1] - oy) * iy, by = (A.root_mx[1] - oy) * iy;
+            const double az = (A.root_mn[2] - oz) * iz, bz = (A.root_mx[2] - oz) * iz;
+            const double t_enter = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
+            const double t_exit = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
+            if (!(fmax(t_enter, 0.001) <= t_exit)) i = n; // misses the scene
+            t0 = t_enter > 0.0 ? t_enter : 0.0;
+            sr = rtdev::slab_ray((float)(fma(t0, dx, ox) - A.center[0]), (float)(fma(t0, dy, oy) - A.center[1]),
+                                 (float)(fma(t0, dz, oz) - A.center[2]), ix, iy, iz);
+            tmin_f = (float)(0.001 - t0) - fabsf((float)(0.001 - t0)) * slack - 0x1p-126f;
+            best_f = __builtin_inff();
+        };
+        if constexpr (PREFETCH) {
+            // PREFETCHED refill, what a real trace kernel would do: every lane keeps its NEXT ray loaded beside the one it
+            // walks, so a lane whose ray is through goes on at once; the queue counter is asked one round ahead of the
+            // loads and the loads a ray ahead of their use, so neither latency is waited for.
+            n_starts += __ballot(ray < 0 && next_index >= 0) != 0;
+            if (ray < 0 && next_index >= 0) { // 1. take the prefetched ray
+                start(next_index, next_ray);
+                next_index = -1;
+            }
+            if (asked) { // 2. the indices asked for LAST round have arrived: load those rays
+                const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)asked_base);
+                if (base + asked_count >= limit) queue_dry = true;
+                if (want) {
+                    const unsigned mine = base + want_rank;
+                    if (mine < limit) {
+                        next_index = (int)mine;
+                        next_ray = A.rays[mine];
+                    }
+                    want = false;
+                }
+                asked = false;
+            }
+            const uint64_t empty = __ballot(next_index < 0); // 3. ask for indices for the empty prefetch slots
+            const int n_empty = __popcll(empty);
+            if (!queue_dry && (n_empty >= A.fetch_min || n_empty == 64)) {
+                asked_base = take((unsigned)n_empty);
+                asked_count = (unsigned)n_empty;
+                asked = true;
+                if (next_index < 0) {
+                    want = true;
+                    want_rank = (unsigned)lane_rank(empty);
+                }
+            }
+            if (__ballot(ray >= 0 || next_index >= 0) == 0 && !asked) break;
+        } else {
         // ---- hand out rays
         const bool idle = ray < 0;
         const uint64_t idle_mask = __ballot(idle);
@@ -71,38 +161,16 @@ __global__ __launch_bounds__(256, 4) void k_walk(const Args A) {
         // wait for memory every round (measured: 2.4 x SLOWER than pinned rays), so lanes are refilled fetch_min at a time
         const bool fetch = !queue_dry && (A.mode == 0 ? n_idle == 64 : (n_idle >= A.fetch_min || n_idle == 64));
         if (fetch) {
-            unsigned base = 0;
-            if (lane == 0) base = atomicAdd(A.queue, (unsigned)n_idle);
-            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-            if (base + (unsigned)n_idle >= (unsigned)A.n_rays) queue_dry = true;
+            ++n_starts;
+            const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)take((unsigned)n_idle));
+            if (base + (unsigned)n_idle >= limit) queue_dry = true;
             const unsigned mine = base + (unsigned)lane_rank(idle_mask);
-            if (idle && mine < (unsigned)A.n_rays) {
-                ray = (int)mine;
-                const Ray R = A.rays[mine];
-                ox = R.o[0]; oy = R.o[1]; oz = R.o[2];
-                dx = R.d[0]; dy = R.d[1]; dz = R.d[2];
-                time = R.time;
-                inv_a = 1.0 / (dx * dx + dy * dy + dz * dz);
-                best_t = __builtin_inf();
-                best = -1;
-                i = 0;
-                // closest_hit_bvh's prologue: clip to the root box in f64, then f32 around the root's centre
-                const double ix = 1.0 / dx, iy = 1.0 / dy, iz = 1.0 / dz;
-                const double ax = (A.root_mn[0] - ox) * ix, bx = (A.root_mx[0] - ox) * ix;
-                const double ay = (A.root_mn[1] - oy) * iy, by = (A.root_mx[1] - oy) * iy;
-                const double az = (A.root_mn[2] - oz) * iz, bz = (A.root_mx[2] - oz) * iz;
-                const double t_enter = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
-                const double t_exit = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
-                if (!(fmax(t_enter, 0.001) <= t_exit)) i = n; // misses the scene
-                t0 = t_enter > 0.0 ? t_enter : 0.0;
-                sr = rtdev::slab_ray((float)(fma(t0, dx, ox) - A.center[0]), (float)(fma(t0, dy, oy) - A.center[1]),
-                                     (float)(fma(t0, dz, oz) - A.center[2]), ix, iy, iz);
-                tmin_f = (float)(0.001 - t0) - fabsf((float)(0.001 - t0)) * slack - 0x1p-126f;
-                best_f = __builtin_inff();
-            }
+            if (idle && mine < limit) start((int)mine, A.rays[mine]);
         }
         if (__ballot(ray >= 0) == 0) break; // queue dry and nothing in flight
+        }
         if (++guard > (1u << 22)) break;
+        ++n_rounds;
         // ---- descent: until every lane with a ray stands at a leaf or has left the tree (or few still descend)
         int count = 0, first = 0;
         for (;;) {
@@ -110,6 +178,7 @@ __global__ __launch_bounds__(256, 4) void k_walk(const Args A) {
             const int n_walking = __popcll(__ballot(walking));
             if (n_walking == 0) break;
             if (A.mode == 2 && n_walking <= A.straggle && __ballot(ray >= 0 && count > 0) != 0) break;
+            ++n_descents;
             if (walking) {
                 const uint4 *raw = reinterpret_cast<const uint4 *>(&nodes[i]);
                 const uint4 q0 = raw[0], q1 = raw[1];
@@ -124,6 +193,7 @@ __global__ __launch_bounds__(256, 4) void k_walk(const Args A) {
         }
         // ---- leaves
         for (int k = 0; __ballot(ray >= 0 && k < count) != 0; ++k) {
+            ++n_leaves;
             if (ray >= 0 && k < count) {
                 const Sphere S = A.spheres[first + k];
                 const double cx = S.c0[0] + time * S.dc[0], cy = S.c0[1] + time * S.dc[1], cz = S.c0[2] + time * S.dc[2];
@@ -151,6 +221,12 @@ __global__ __launch_bounds__(256, 4) void k_walk(const Args A) {
             ray = -1;
         }
         // (a lane that broke out of the descent at a leaf has count > 0 handled above and goes on descending next round)
+    }
+    if (lane == 0) {
+        atomicAdd(&A.stats[0], (unsigned long long)n_rounds);
+        atomicAdd(&A.stats[1], (unsigned long long)n_descents);
+        atomicAdd(&A.stats[2], (unsigned long long)n_leaves);
+        atomicAdd(&A.stats[3], (unsigned long long)n_starts);
     }
 }
 
@@ -246,6 +322,7 @@ int main(int argc, char **argv) {
     CK(hipMalloc((void **)&d_spheres, hs.spheres.size() * sizeof(Sphere)));
     CK(hipMemcpy(d_spheres, hs.spheres.data(), hs.spheres.size() * sizeof(Sphere), hipMemcpyHostToDevice));
     CK(hipMalloc((void **)&a.queue, sizeof(unsigned)));
+    CK(hipMalloc((void **)&a.stats, 4 * sizeof(unsigned long long)));
     a.nodes = d_nodes;
     a.spheres = d_spheres;
     a.n_nodes = (int)hs.bvh.nodes.size();
@@ -267,24 +344,36 @@ int main(int argc, char **argv) {
         a.hits = d_hits;
         a.n_rays = (int)rays.size();
         std::vector<Hit> ref;
-        struct Case { int mode, straggle, fetch_min; const char *name; };
-        const Case cases[] = {{0, 0, 64, "64 rays pinned to a wave's lanes (today)"},
-                              {1, 0, 1, "lanes refilled one by one"},
-                              {1, 0, 8, "refilled once 8 lanes are idle"},
-                              {1, 0, 16, "refilled once 16 lanes are idle"},
-                              {1, 0, 32, "refilled once 32 lanes are idle"},
-                              {2, 8, 16, "16 idle; leaves once <= 8 lanes descend"},
-                              {2, 16, 16, "16 idle; leaves once <= 16 lanes descend"}};
+        struct Case { int mode, straggle, fetch_min, own; const char *name; };
+        const Case cases[] = {{0, 0, 64, 0, "64 rays pinned to a wave's lanes (today)"},
+                              {1, 0, 1, 0, "lanes refilled one by one"},
+                              {1, 0, 8, 0, "refilled once 8 lanes are idle"},
+                              {1, 0, 16, 0, "refilled once 16 lanes are idle"},
+                              {1, 0, 32, 0, "refilled once 32 lanes are idle"},
+                              {2, 8, 16, 0, "16 idle; leaves once <= 8 lanes descend"},
+                              {3, 0, 1, 0, "PREFETCHED next ray per lane, one by one"},
+                              {3, 0, 16, 0, "prefetched, asked once 16 slots are empty"},
+                              {0, 0, 64, 1, "OWN SHARE per wave, no atomic: pinned"},
+                              {1, 0, 1, 1, "own share: refilled one by one"},
+                              {1, 0, 8, 1, "own share: refilled once 8 lanes are idle"},
+                              {1, 0, 16, 1, "own share: refilled once 16 lanes are idle"},
+                              {1, 0, 32, 1, "own share: refilled once 32 lanes are idle"},
+                              {2, 8, 16, 1, "own share: 16 idle; leaves once <= 8 descend"},
+                              {3, 0, 1, 1, "own share: prefetched, one by one"},
+                              {3, 0, 16, 1, "own share: prefetched, 16 slots"}};
         for (const Case &c : cases) {
             a.mode = c.mode;
             a.straggle = c.straggle;
             a.fetch_min = c.fetch_min;
+            a.own_range = c.own;
             float best_ms = 1e30f;
             for (int rep = 0; rep < 3; ++rep) {
                 CK(hipMemset(a.queue, 0, sizeof(unsigned)));
+                CK(hipMemset(a.stats, 0, 4 * sizeof(unsigned long long)));
                 CK(hipMemset(d_hits, 0xff, rays.size() * sizeof(Hit)));
                 CK(hipEventRecord(e0));
-                hipLaunchKernelGGL(k_walk, dim3(256 * 4), dim3(256), lds, 0, a);
+                if (a.mode == 3) hipLaunchKernelGGL(k_walk<true>, dim3(256 * 4), dim3(256), lds, 0, a);
+                else hipLaunchKernelGGL(k_walk<false>, dim3(256 * 4), dim3(256), lds, 0, a);
                 CK(hipGetLastError());
                 CK(hipEventRecord(e1));
                 CK(hipEventSynchronize(e1));
@@ -295,10 +384,20 @@ int main(int argc, char **argv) {
             std::vector<Hit> got(rays.size());
             CK(hipMemcpy(got.data(), d_hits, rays.size() * sizeof(Hit), hipMemcpyDeviceToHost));
             long differ = 0;
-            if (c.mode == 0) ref = got;
-            else for (size_t k = 0; k < got.size(); ++k) differ += got[k].prim != ref[k].prim || got[k].t != ref[k].t;
+            if (c.mode == 0 && !c.own) ref = got;
+            else for (size_t k = 0; k < got.size(); ++k) {
+                const bool bad = got[k].prim != ref[k].prim || got[k].t != ref[k].t;
+                if (bad && differ < 4) printf("  ray %zu: prim %d t %.17g, pinned walk prim %d t %.17g\n", k, got[k].prim, got[k].t, ref[k].prim, ref[k].t);
+                differ += bad;
+            }
+            if (differ) printf("  %ld of %zu rays differ\n", differ, got.size());
             printf("%-8s rays | %-44s %7.2f ms  %6.2f G rays/s%s\n", set == 0 ? "primary" : "bounce", c.name, best_ms,
-                   rays.size() / best_ms / 1e6, c.mode == 0 ? "" : (differ ? "  RESULTS DIFFER" : "  same hits"));
+                   rays.size() / best_ms / 1e6, (c.mode == 0 && !c.own) ? "" : (differ ? "  RESULTS DIFFER" : "  same hits"));
+            unsigned long long st[4];
+            CK(hipMemcpy(st, a.stats, sizeof st, hipMemcpyDeviceToHost));
+            const double per = 64.0 / (double)rays.size(); // wave-level issues per 64 rays: 1 wave with no idle lane walks 64 rays
+            printf("           per 64 rays: %6.1f rounds, %6.1f descent steps, %6.1f leaf tests, %5.2f prologues issued\n", st[0] * per,
+                   st[1] * per, st[2] * per, st[3] * per);
         }
         CK(hipFree(d_rays));
         CK(hipFree(d_hits));
