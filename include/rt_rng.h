@@ -15,6 +15,19 @@
  *     u53(hi, lo) = (((uint64)hi << 32 | lo) >> 11) * 2^-53      in [0,1)
  *
  * and `random_double_range(a,b)` (util.rs:14-17) is  a + (b - a) * d.
+ *
+ * One purpose packs THREE draws into a block, at 42 bits each (RT_RNG_SCATTER below):
+ *
+ *     e_j  = u42(out[j], out[3] >> 10 j)      j = 0, 1, 2
+ *     u42(w, t) = ((uint64)w << 10 | (t & 0x3FF)) * 2^-42         in [0,1)
+ *
+ * A candidate of random_in_unit_sphere is three coordinates, and the rejection loop's candidates are
+ * the largest single consumer of random bits on the path (two blocks per candidate were a quarter of
+ * the cornell_box frame's instructions).  The reference's own `gen_range(-1.0..1.0)` (rand 0.8
+ * UniformFloat: 52 random mantissa bits, scaled) puts a coordinate on a grid of 2^-51; e_j puts it on
+ * a grid of 2^-41.  Nothing the path computes from a candidate can tell the two apart: the acceptance
+ * test |p|^2 < 1 changes its answer for a fraction ~2^-40 of candidates, a direction moves by at most
+ * 2^-41.  Every other draw keeps 53 bits.
  * Because nothing depends on how many draws came before, a lane never
  * carries generator state, dead draws (lens disk with aperture 0, Metal with
  * fuzz 0, ray time with no moving geometry) can be skipped on the device
@@ -41,8 +54,7 @@
 #define RT_RNG_LENS 2       /* block i: x = R(-1,1)(d0),      util.rs:25-39 iteration i      */
                             /*          y = R(-1,1)(d1)                                      */
 #define RT_RNG_SCATTER 3    /* iteration i of random_in_unit_sphere (vec3.rs:424-430):       */
-                            /*   block 2i  : x = R(-1,1)(d0), y = R(-1,1)(d1)                */
-                            /*   block 2i+1: z = R(-1,1)(d0)                                 */
+                            /*   block i: x = R(-1,1)(e0), y = R(-1,1)(e1), z = R(-1,1)(e2)  */
                             /* used by Lambertian (lambertian.rs:27) and Metal (metal.rs:34) */
 #define RT_RNG_DIELECTRIC 4 /* block 0: d0                    dialectric.rs:44               */
 #define RT_RNG_PERLIN 5     /* host: pixel = gradient index, sample = RT_RNG_SAMPLE_TABLE,   */

@@ -11,7 +11,7 @@
  * (racer-tracer/src/vec3.rs:446-503).  Those are replayed in
  * tests/test_oracle_reference_vectors.py together with everything the
  * reference itself PRODUCED, its five 600x600 SavePng screenshots
- * (assets/*.png, committed as values in tests/golden/reference_assets.json):
+ * (the PNGs under assets/, committed as values in tests/golden/reference_assets.json):
  * sky pixels of three_balls.png / noise_and_textures.png exactly; 4x4 and 8x8
  * block means of clown.png (< 0.001), three_balls.png (< 0.004) and of
  * noise_and_textures.png outside its randomly seeded Perlin sphere (< 0.01);
@@ -41,6 +41,9 @@ void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, ui
 /* d0 (which=0) or d1 (which=1) of the addressed block */
 double orc_rng_double(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t segment,
                       uint32_t purpose, uint32_t block, int which);
+/* e_0, e_1, e_2 of the addressed block (the three 42-bit draws of a random_in_unit_sphere candidate) */
+void orc_rng_triple(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t segment,
+                    uint32_t purpose, uint32_t block, double e[3]);
 
 /* ---- Vec3 operators exactly as vec3.rs defines them (for the reference's
  *      own unit tests and the KATs) ---- */

@@ -40,6 +40,7 @@ _PROTOS = {
     "orc_philox4x32": (None, [_P(C.c_uint32), _P(C.c_uint32), C.c_int, _P(C.c_uint32)]),
     "orc_rng_double": (_D, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                             C.c_uint32, C.c_int]),
+    "orc_rng_triple": (None, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _PD]),
     "orc_vec3_add": (None, [_PD, _PD, _PD]),
     "orc_vec3_sub": (None, [_PD, _PD, _PD]),
     "orc_vec3_mul": (None, [_PD, _PD, _PD]),

@@ -4,7 +4,8 @@
  * (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2,
  * 3", SC'11); it replaces `rand 0.8.5`'s ThreadRng that the reference calls
  * at racer-tracer/src/util.rs:9-23 (that crate is not in /root/reference and
- * is unseedable, so only its distribution is matched: 53-bit uniform [0,1)).
+ * is unseedable, so only its distribution is matched: 53-bit uniform [0,1);
+ * the three coordinates of a rejection-sphere candidate at 42 bits each, rt_rng.h).
  * Pinned by the Random123 known-answer vectors in
  * tests/test_oracle_reference_vectors.py.
  */
@@ -46,4 +47,17 @@ double orc_rng_double(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t s
     uint32_t out[4];
     orc_philox4x32(ctr, key, RT_PHILOX_ROUNDS, out);
     return which ? u53(out[2], out[3]) : u53(out[0], out[1]);
+}
+
+/* e_0, e_1, e_2 of the addressed block: three 42-bit uniforms (include/rt_rng.h) */
+void orc_rng_triple(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t segment,
+                    uint32_t purpose, uint32_t block, double e[3]) {
+    uint32_t ctr[4] = { pixel, sample, (segment << 8) | purpose, block };
+    uint32_t key[2] = { (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32) };
+    uint32_t out[4];
+    orc_philox4x32(ctr, key, RT_PHILOX_ROUNDS, out);
+    for (int j = 0; j < 3; ++j) {
+        uint64_t u = ((uint64_t)out[j] << 10) | (uint64_t)((out[3] >> (10 * j)) & 0x3FFu);
+        e[j] = (double)u * (1.0 / 4398046511104.0); /* 2^-42 */
+    }
 }

@@ -93,9 +93,9 @@ static V3 random_in_unit_disk(const PathRng *r) {
 /* vec3.rs:424-430 random_in_unit_sphere */
 static V3 random_in_unit_sphere(const PathRng *r, uint32_t segment) {
     for (uint32_t i = 0;; ++i) {
-        V3 p = v3(range(-1.0, 1.0, draw(r, segment, RT_RNG_SCATTER, 2 * i, 0)),
-                  range(-1.0, 1.0, draw(r, segment, RT_RNG_SCATTER, 2 * i, 1)),
-                  range(-1.0, 1.0, draw(r, segment, RT_RNG_SCATTER, 2 * i + 1, 0)));
+        double e[3]; /* Vec3::random_range(-1, 1): the candidate's three draws share block i */
+        orc_rng_triple(r->seed, r->pixel, r->sample, segment, RT_RNG_SCATTER, i, e);
+        V3 p = v3(range(-1.0, 1.0, e[0]), range(-1.0, 1.0, e[1]), range(-1.0, 1.0, e[2]));
         if (length_squared(p) >= 1.0) continue;
         return p;
     }

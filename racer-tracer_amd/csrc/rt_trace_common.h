@@ -200,6 +200,18 @@ __device__ __forceinline__ double sym53(uint32_t hi, uint32_t lo) {
     return D - c;
 }
 
+// The three coordinates of a random_in_unit_sphere candidate from ONE block (rt_rng.h, RT_RNG_SCATTER): coordinate j is
+// random_double_range(-1, 1) of the 42-bit uniform d_j = U_j * 2^-42, U_j = out[j] << 10 | (out[3] >> 10 j & 0x3FF).
+// D = 2 * (1 + U * 2^-42) is assembled from bits (exponent of [2, 4), mantissa U << 10) and -1 + 2 d = D - 3, exactly.
+__device__ __forceinline__ double sym42(uint32_t w, uint32_t t_at_10) { // t_at_10: the ten extra bits at bits 10..19
+    const uint32_t d_hi = 0x40000000u | (w >> 12);
+    const uint32_t d_lo = (w << 20) | t_at_10;
+    return __longlong_as_double((long long)(((unsigned long long)d_hi << 32) | d_lo)) - 3.0;
+}
+__device__ __forceinline__ d3 sphere_candidate(const u4 &b) {
+    return mk(sym42(b.a, (b.d << 10) & 0x000FFC00u), sym42(b.b, b.d & 0x000FFC00u), sym42(b.c, (b.d >> 10) & 0x000FFC00u));
+}
+
 struct PathRng {
     uint32_t pixel, sample, k0, k1;
     __device__ __forceinline__ u4 block(uint32_t segment, uint32_t purpose, uint32_t blk) const {
@@ -210,10 +222,7 @@ struct PathRng {
 // vec3.rs:424-430 random_in_unit_sphere under the addressed-draw contract
 __device__ __forceinline__ d3 random_in_unit_sphere(const PathRng &rng, uint32_t segment) {
     for (uint32_t i = 0;; ++i) {
-        u4 b0 = rng.block(segment, RT_RNG_SCATTER, 2 * i);
-        u4 b1 = rng.block(segment, RT_RNG_SCATTER, 2 * i + 1);
-        d3 p = mk(sym53(b0.a, b0.b), sym53(b0.c, b0.d),
-                  sym53(b1.a, b1.b));
+        d3 p = sphere_candidate(rng.block(segment, RT_RNG_SCATTER, i));
         if (len2(p) >= 1.0) continue;
         return p;
     }

@@ -26,8 +26,8 @@
 //    loops until a candidate falls inside the sphere; per lane that is 1.9
 //    iterations on average but a wave pays for its slowest lane (~6.4).
 //    Because every draw is ADDRESSED (include/rt_rng.h) — candidate i of a
-//    path is a pure function of (pixel, sample, segment, i) — any lane can
-//    evaluate any lane's candidate.  Each round the lanes that still need a
+//    path is a pure function of (pixel, sample, segment, i): ONE Philox block,
+//    three 42-bit coordinates — any lane can evaluate any lane's candidate.  Each round the lanes that still need a
 //    sample post a request in LDS, the 64 lanes split into groups that test
 //    consecutive candidates of one request each, and a ballot picks the first
 //    accepted candidate in stream order.  ~3 rounds instead of ~6.4, identical
@@ -189,18 +189,17 @@ __device__ __forceinline__ bool coop_random_in_unit_sphere(bool need, uint32_t p
     uint64_t pending = __ballot(need);
     for (int round = 0; round < max_rounds && pending != 0; ++round) {
         const int n = __popcll(pending);
-        // a round costs the whole wave ~110 instructions; past the first it only runs while enough requests are
-        // open to be worth that (the others resume next iteration): C2 +2.2 %, C3 +0.3 % (thresholds 2..12 measured)
+        // a round costs the whole wave ~70 instructions; past the first it only runs while enough requests are
+        // open to be worth that (the others resume next iteration): C2 +2.2 %, C3 +0.3 % (thresholds 2..16 and one to
+        // six rounds measured again with one-block candidates: 8 and two rounds stay)
         if (round > 0 && n < 8) break;
         // group size q = 2^lg, the largest power of two with n * q <= 64
         const int lg = n > 32 ? 0 : (n > 16 ? 1 : (n > 8 ? 2 : (n > 4 ? 3 : (n > 2 ? 4 : (n > 1 ? 5 : 6)))));
         if (lg == 0) { // more than 32 requests: one candidate each, so every lane tests its OWN (no LDS, no shuffle)
             if (need) {
-                const u4 b0 = philox4x32(pixel, sample, (seg << 8) | RT_RNG_SCATTER, 2u * base, k0, k1);
-                const u4 b1 = philox4x32(pixel, sample, (seg << 8) | RT_RNG_SCATTER, 2u * base + 1u, k0, k1);
                 // `result` only means something to a lane that returns true: a lane that still needs a sample
                 // may take every candidate it looks at, rejected ones included, without a select
-                result = mk(sym53(b0.a, b0.b), sym53(b0.c, b0.d), sym53(b1.a, b1.b));
+                result = sphere_candidate(philox4x32(pixel, sample, (seg << 8) | RT_RNG_SCATTER, base, k0, k1));
                 if (len2(result) < 1.0) {
                     need = false;
                     have = true;
@@ -217,10 +216,8 @@ __device__ __forceinline__ bool coop_random_in_unit_sphere(bool need, uint32_t p
         const int c = lane & ((1 << lg) - 1);  // candidate offset inside the group
         const bool serving = j < n;
         const Req4 r = req[serving ? j : 0];
-        const uint32_t i = r.w + (uint32_t)c;  // candidate index: blocks 2i and 2i+1 (rt_rng.h)
-        const u4 b0 = philox4x32(r.x, r.y, (r.z << 8) | RT_RNG_SCATTER, 2u * i, k0, k1);
-        const u4 b1 = philox4x32(r.x, r.y, (r.z << 8) | RT_RNG_SCATTER, 2u * i + 1u, k0, k1);
-        const d3 p = mk(sym53(b0.a, b0.b), sym53(b0.c, b0.d), sym53(b1.a, b1.b));
+        const uint32_t i = r.w + (uint32_t)c;  // candidate index = its block (rt_rng.h)
+        const d3 p = sphere_candidate(philox4x32(r.x, r.y, (r.z << 8) | RT_RNG_SCATTER, i, k0, k1));
         const uint64_t accepted = __ballot(serving && len2(p) < 1.0);
         // first accepted candidate of my own request, in stream order
         const int first = need ? (rank << lg) : 0;

@@ -96,6 +96,37 @@ def test_rng_double_is_53_bit_of_addressed_block(orc):
         assert got == want and 0.0 <= got < 1.0
 
 
+def test_rng_triple_is_three_42_bit_draws_of_one_block(orc):
+    """include/rt_rng.h: e_j = u42(out[j], out[3] >> 10 j) — the three coordinates of a random_in_unit_sphere candidate."""
+    seed, pixel, sample, seg, purpose, block = 0x0123456789ABCDEF, 77, 5, 3, 3, 9
+    out = (C.c_uint32 * 4)()
+    orc.lib().orc_philox4x32((C.c_uint32 * 4)(pixel, sample, (seg << 8) | purpose, block),
+                             (C.c_uint32 * 2)(seed & 0xffffffff, seed >> 32), CONTRACT_ROUNDS, out)
+    e = (C.c_double * 3)()
+    orc.lib().orc_rng_triple(seed, pixel, sample, seg, purpose, block, e)
+    for j in range(3):
+        want = float((out[j] << 10) | ((out[3] >> (10 * j)) & 0x3FF)) * 2.0 ** -42
+        assert e[j] == want and 0.0 <= e[j] < 1.0
+
+
+def test_rng_triple_candidates_fill_the_unit_sphere_like_independent_uniforms(orc):
+    """The 42-bit coordinates share a block (and the ten low bits of each come from ONE word): accepted candidates
+    must still be uniform in the ball — acceptance pi/6, zero mean, E[x^2] = 1/5, no correlation between axes."""
+    e = (C.c_double * 3)()
+    pts = np.empty((60000, 3))
+    for i in range(len(pts)):
+        orc.lib().orc_rng_triple(1, i, 3, 1, 3, 0, e)
+        pts[i] = (-1.0 + 2.0 * e[0], -1.0 + 2.0 * e[1], -1.0 + 2.0 * e[2])
+    assert abs(pts.mean(axis=0)).max() < 0.01 and abs(pts.var(axis=0) - 1 / 3).max() < 0.01
+    inside = pts[(pts ** 2).sum(axis=1) < 1.0]
+    assert abs(len(inside) / len(pts) - np.pi / 6) < 0.008                      # sigma = 0.002
+    assert abs(inside.mean(axis=0)).max() < 0.01 and abs((inside ** 2).mean(axis=0) - 0.2).max() < 0.005
+    assert abs(np.corrcoef(inside.T) - np.eye(3)).max() < 0.02
+    # the ten low bits of the three coordinates are disjoint slices of out[3]: pairwise independent
+    low = np.round((pts + 1.0) * 2.0 ** 41).astype(np.int64) & 0x3FF
+    assert abs(np.corrcoef(low.T.astype(float)) - np.eye(3)).max() < 0.02
+
+
 def test_rng_uniformity(orc):
     xs = np.array([orc.lib().orc_rng_double(1, i, 0, 0, 1, 0, 0) for i in range(20000)])
     assert abs(xs.mean() - 0.5) < 0.01 and abs(xs.var() - 1 / 12) < 0.005
