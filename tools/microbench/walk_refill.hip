@@ -37,6 +37,7 @@ struct Args {
     unsigned int *queue;
     unsigned long long *stats; // [4] wave-level counts: rounds, descent iterations, leaf iterations, prologues
     int n_nodes, n_rays, mode, straggle, fetch_min;
+    int mode_arg;  // mode 4: helpers are also handed work every mode_arg descent steps (0: only between rounds)
     int own_range; // 1: every wave takes rays from its OWN contiguous share (a counter in a register, no atomic at all)
     double root_mn[3], root_mx[3], center[3];
 };
@@ -230,6 +231,179 @@ template <bool PREFETCH> __global__ __launch_bounds__(256, 4) void k_walk(const 
     }
 }
 
+
+// ---- mode 4: 64 rays pinned to a wave, and lanes whose ray is through HELP the lanes that are not
+// A skip-link walk is a walk over a RANGE of the node array: [i, e) with e = the array's end.  The node after node i's
+// subtree is nodes[i].skip, so a lane at node i whose range goes on past that subtree can hand [skip, e) to an idle lane
+// (a copy of its ray, its closest hit so far as the helper's culling bound) and keep [i, skip) — whole subtrees on both
+// sides, no stack, and the closest hit is the minimum over everybody who walked a part of the ray's range (merged
+// through LDS once the wave is through).  The same hits as the undivided walk: every primitive is tested by the same
+// code against the same ray; only which lane does it changes.
+template <typename T> __device__ __forceinline__ T take_from(T v, int src) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "");
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(T, __shfl(__builtin_bit_cast(int, v), src, 64));
+    } else {
+        const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+        const unsigned lo = (unsigned)__shfl((int)(unsigned)u, src, 64), hi = (unsigned)__shfl((int)(unsigned)(u >> 32), src, 64);
+        return __builtin_bit_cast(T, ((unsigned long long)hi << 32) | lo);
+    }
+}
+
+__global__ __launch_bounds__(256, 4) void k_walk_donate(const Args A) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    rtdev::BvhNode *nodes = reinterpret_cast<rtdev::BvhNode *>(lds);
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(A.nodes);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds);
+        for (int i = threadIdx.x; i < A.n_nodes * 2; i += 256) dst[i] = src[i];
+    }
+    // per wave behind the nodes: the rays' merged closest hits and the table that pairs idle lanes with donors
+    struct Merge { unsigned long long t_bits[64]; unsigned prim[64]; int donor[64]; };
+    Merge &M = reinterpret_cast<Merge *>(lds + (size_t)A.n_nodes * sizeof(rtdev::BvhNode))[threadIdx.x >> 6];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int n = A.n_nodes;
+    const float slack = 0x1p-20f;
+    const unsigned n_waves = gridDim.x * (blockDim.x >> 6), wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const unsigned share = ((unsigned)A.n_rays + n_waves - 1) / n_waves;
+    unsigned own_next = wave * share;
+    const unsigned own_end = min(own_next + share, (unsigned)A.n_rays);
+    unsigned n_rounds = 0, n_descents = 0, n_leaves = 0, n_gifts = 0;
+    for (; own_next < own_end; own_next += 64) {
+        const unsigned mine = own_next + (unsigned)lane;
+        const bool have = mine < own_end;
+        const Ray R = A.rays[have ? mine : own_next];
+        double ox = R.o[0], oy = R.o[1], oz = R.o[2], dx = R.d[0], dy = R.d[1], dz = R.d[2], time = R.time;
+        double inv_a = rcp_fast(dx * dx + dy * dy + dz * dz);
+        double best_t = __builtin_inf();
+        int best = -1, i = 0, e = n, owner = lane;
+        const double ix = rcp_fast(dx), iy = rcp_fast(dy), iz = rcp_fast(dz);
+        const double ax = (A.root_mn[0] - ox) * ix, bx = (A.root_mx[0] - ox) * ix;
+        const double ay = (A.root_mn[1] - oy) * iy, by = (A.root_mx[1] - oy) * iy;
+        const double az = (A.root_mn[2] - oz) * iz, bz = (A.root_mx[2] - oz) * iz;
+        const double t_enter = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
+        const double t_exit = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
+        if (!have || !(fmax(t_enter, 0.001) <= t_exit)) i = n; // no ray, or it misses the scene
+        double t0 = t_enter > 0.0 ? t_enter : 0.0;
+        rtdev::SlabRay sr = rtdev::slab_ray((float)(fma(t0, dx, ox) - A.center[0]), (float)(fma(t0, dy, oy) - A.center[1]),
+                                            (float)(fma(t0, dz, oz) - A.center[2]), ix, iy, iz);
+        float tmin_f = (float)(0.001 - t0) - fabsf((float)(0.001 - t0)) * slack - 0x1p-126f;
+        float best_f = __builtin_inff();
+        M.t_bits[lane] = 0x7ff0000000000000ull; // +inf
+        M.prim[lane] = 0xffffffffu;
+        // A lane's (best_t, best) is a hit of the ray of `owner` if best >= 0.  t > 0, so its bits order like the value.
+        auto hand_in = [&](bool who) {
+            const bool found = who && best >= 0;
+            if (found) atomicMin(&M.t_bits[owner], (unsigned long long)__double_as_longlong(best_t));
+            // whoever holds the minimum names its primitive (an earlier, farther hit's name is overwritten)
+            if (found && M.t_bits[owner] == (unsigned long long)__double_as_longlong(best_t)) M.prim[owner] = (unsigned)best;
+        };
+        // ---- lanes without work take a part of somebody's range (callable wherever no lane stands at a leaf it has
+        // not tested yet... or does: a lane with count > 0 neither gives nor takes)
+        auto donate = [&](int count_now) {
+            const uint64_t has_range = __ballot(i < e);
+            const uint64_t free_lanes = __ballot(!(i < e) && count_now == 0);
+            const int n_idle = __popcll(free_lanes);
+            if (n_idle < A.fetch_min) return;
+            int m = n;
+            if (i < e && count_now == 0) m = (int)reinterpret_cast<const uint4 *>(&nodes[i])[1].z; // the node after node i's subtree
+            const bool can = i < e && count_now == 0 && m < e && e - m >= A.straggle;
+            const uint64_t donors = __ballot(can);
+            if (donors == 0) return;
+            (void)has_range;
+            const int n_don = __popcll(donors);
+            if (can) M.donor[lane_rank(donors)] = lane;
+            const bool is_free = !(i < e) && count_now == 0;
+            const int r = lane_rank(free_lanes);
+            const bool take = is_free && r < n_don;
+            const bool gives = can && lane_rank(donors) < n_idle;
+            const int src = take ? M.donor[r] : lane;
+            const double g_ox = take_from(ox, src), g_oy = take_from(oy, src), g_oz = take_from(oz, src);
+            const double g_dx = take_from(dx, src), g_dy = take_from(dy, src), g_dz = take_from(dz, src);
+            const double g_time = take_from(time, src), g_inv_a = take_from(inv_a, src), g_best_t = take_from(best_t, src);
+            const double g_t0 = take_from(t0, src);
+            const float g_ivx = take_from(sr.ivx, src), g_ivy = take_from(sr.ivy, src), g_ivz = take_from(sr.ivz, src);
+            const float g_oix = take_from(sr.oix, src), g_oiy = take_from(sr.oiy, src), g_oiz = take_from(sr.oiz, src);
+            const float g_tmin = take_from(tmin_f, src), g_bestf = take_from(best_f, src);
+            const int g_e = take_from(e, src), g_m = take_from(m, src), g_owner = take_from(owner, src);
+            hand_in(take); // what a helper found for the ray it worked on before goes to that ray's owner first
+            if (take) {
+                best = -1;
+                ox = g_ox; oy = g_oy; oz = g_oz; dx = g_dx; dy = g_dy; dz = g_dz;
+                time = g_time; inv_a = g_inv_a; best_t = g_best_t; t0 = g_t0;
+                sr.ivx = g_ivx; sr.ivy = g_ivy; sr.ivz = g_ivz; sr.oix = g_oix; sr.oiy = g_oiy; sr.oiz = g_oiz;
+                tmin_f = g_tmin; best_f = g_bestf;
+                i = g_m; e = g_e; owner = g_owner;
+            }
+            if (gives) e = m;
+            n_gifts += (unsigned)min(n_don, n_idle);
+        };
+        for (unsigned guard = 0; guard < (1u << 20); ++guard) {
+            const uint64_t busy = __ballot(i < e);
+            if (busy == 0) break;
+            ++n_rounds;
+            donate(0);
+            // ---- descent
+            int count = 0, first = 0;
+            unsigned step = 0;
+            for (;;) {
+                const bool walking = i < e && count == 0;
+                if (__ballot(walking) == 0) break;
+                ++n_descents;
+                if (walking) {
+                    const uint4 *raw = reinterpret_cast<const uint4 *>(&nodes[i]);
+                    const uint4 q0 = raw[0], q1 = raw[1];
+                    const float mn[3] = {__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)};
+                    const float mx[3] = {__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)};
+                    const int skip = (int)q1.z, fc = (int)q1.w;
+                    const bool hit = rtdev::slab_hit(mn, mx, sr, tmin_f, best_f, slack);
+                    i = hit ? i + 1 : skip;
+                    count = hit ? (fc & 7) : 0;
+                    first = fc >> 3;
+                }
+                if (A.mode_arg > 0 && (++step % (unsigned)A.mode_arg) == 0) donate(count);
+            }
+            // ---- leaves
+            for (int k = 0; __ballot(k < count) != 0; ++k) {
+                ++n_leaves;
+                if (k < count) {
+                    const Sphere S = A.spheres[first + k];
+                    const double cx = S.c0[0] + time * S.dc[0], cy = S.c0[1] + time * S.dc[1], cz = S.c0[2] + time * S.dc[2];
+                    const double px = ox - cx, py = oy - cy, pz = oz - cz;
+                    const double a = dx * dx + dy * dy + dz * dz;
+                    const double hb = px * dx + py * dy + pz * dz;
+                    const double c = px * px + py * py + pz * pz - S.r2;
+                    const double disc = hb * hb - a * c;
+                    if (disc >= 0.0) {
+                        const double sq = sqrt(disc);
+                        double root = (-hb - sq) * inv_a;
+                        if (root < 0.001 || best_t < root) root = (-hb + sq) * inv_a;
+                        if (!(root < 0.001 || best_t < root)) {
+                            best_t = root;
+                            best = first + k;
+                            const float f = (float)(best_t - t0);
+                            best_f = f + fabsf(f) * slack;
+                        }
+                    }
+                }
+            }
+        }
+        // ---- merge: the closest hit of a ray is the minimum over the lanes that walked parts of its range
+        hand_in(true);
+        if (have) {
+            const unsigned long long tb = M.t_bits[lane];
+            A.hits[mine] = Hit{__longlong_as_double((long long)tb), (int)M.prim[lane], 0};
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&A.stats[0], (unsigned long long)n_rounds);
+        atomicAdd(&A.stats[1], (unsigned long long)n_descents);
+        atomicAdd(&A.stats[2], (unsigned long long)n_leaves);
+        atomicAdd(&A.stats[3], (unsigned long long)n_gifts);
+    }
+}
+
 struct HostScene {
     std::vector<Sphere> spheres; // leaf order
     rtdev::BvhBuild bvh;
@@ -344,7 +518,7 @@ int main(int argc, char **argv) {
         a.hits = d_hits;
         a.n_rays = (int)rays.size();
         std::vector<Hit> ref;
-        struct Case { int mode, straggle, fetch_min, own; const char *name; };
+        struct Case { int mode, straggle, fetch_min, own; const char *name; int arg = 0; };
         const Case cases[] = {{0, 0, 64, 0, "64 rays pinned to a wave's lanes (today)"},
                               {1, 0, 1, 0, "lanes refilled one by one"},
                               {1, 0, 8, 0, "refilled once 8 lanes are idle"},
@@ -360,19 +534,34 @@ int main(int argc, char **argv) {
                               {1, 0, 32, 1, "own share: refilled once 32 lanes are idle"},
                               {2, 8, 16, 1, "own share: 16 idle; leaves once <= 8 descend"},
                               {3, 0, 1, 1, "own share: prefetched, one by one"},
-                              {3, 0, 16, 1, "own share: prefetched, 16 slots"}};
+                              {3, 0, 16, 1, "own share: prefetched, 16 slots"},
+                              {4, 8, 65, 1, "the helpers' kernel with no lane ever helping"},
+                              {4, 8, 8, 1, "own share: pinned + HELPERS at 8 idle, parts >= 8 nodes"},
+                              {4, 8, 16, 1, "pinned + helpers at 16 idle, parts >= 8 nodes"},
+                              {4, 16, 16, 1, "pinned + helpers at 16 idle, parts >= 16 nodes"},
+                              {4, 4, 24, 1, "pinned + helpers at 24 idle, parts >= 4 nodes"},
+                              {4, 16, 32, 1, "pinned + helpers at 32 idle, parts >= 16 nodes"},
+                              {4, 32, 16, 1, "pinned + helpers at 16 idle, parts >= 32 nodes"},
+                              {4, 8, 16, 1, "helpers at 16 idle, also every 4 descent steps", 4},
+                              {4, 8, 16, 1, "helpers at 16 idle, also every 2 descent steps", 2},
+                              {4, 8, 8, 1, "helpers at 8 idle, also every 4 descent steps", 4},
+                              {4, 4, 8, 1, "helpers at 8 idle, parts >= 4, every 2 steps", 2},
+                              {4, 8, 24, 1, "helpers at 24 idle, also every 4 descent steps", 4},
+                              {4, 8, 32, 1, "helpers at 32 idle, also every 3 descent steps", 3}};
         for (const Case &c : cases) {
             a.mode = c.mode;
             a.straggle = c.straggle;
             a.fetch_min = c.fetch_min;
             a.own_range = c.own;
+            a.mode_arg = c.arg;
             float best_ms = 1e30f;
             for (int rep = 0; rep < 3; ++rep) {
                 CK(hipMemset(a.queue, 0, sizeof(unsigned)));
                 CK(hipMemset(a.stats, 0, 4 * sizeof(unsigned long long)));
                 CK(hipMemset(d_hits, 0xff, rays.size() * sizeof(Hit)));
                 CK(hipEventRecord(e0));
-                if (a.mode == 3) hipLaunchKernelGGL(k_walk<true>, dim3(256 * 4), dim3(256), lds, 0, a);
+                if (a.mode == 4) hipLaunchKernelGGL(k_walk_donate, dim3(256 * 4), dim3(256), lds + 4 * (64 * 8 + 64 * 4 + 64 * 4), 0, a);
+                else if (a.mode == 3) hipLaunchKernelGGL(k_walk<true>, dim3(256 * 4), dim3(256), lds, 0, a);
                 else hipLaunchKernelGGL(k_walk<false>, dim3(256 * 4), dim3(256), lds, 0, a);
                 CK(hipGetLastError());
                 CK(hipEventRecord(e1));
