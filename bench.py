@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5", "random", "boxes", "emissive"])
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (debug)")
+    ap.add_argument("--seed", type=int, default=0, help="override the RNG seed of the config (SURVEY 8(d): seeds 2, 3 for variance)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--pmc", default="live", choices=["live", "file", "none"],
@@ -191,7 +192,7 @@ def live_pmc_summary(args):
     import shutil
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 is not on PATH"
-    child = ["--workload", args.workload] + (["--spp", str(args.spp)] if args.spp else [])
+    child = ["--workload", args.workload] + (["--spp", str(args.spp)] if args.spp else []) + (["--seed", str(args.seed)] if args.seed else [])
     t0 = time.time()
     summary = pmc.collect(child, log=lambda m: sys.stderr.write("bench.py: %s\n" % m), budget_s=150, pass_timeout=60)
     summary["_stamp"]["collected_in_s"] = round(time.time() - t0, 1)
@@ -373,6 +374,8 @@ def main():
     rt = importlib.import_module("racer-tracer_amd")
     host = importlib.import_module("racer-tracer_amd.host")
     session, workload = load_workload(host, args.workload, args.spp)
+    if args.seed:
+        session.params.seed = args.seed
     p = session.params
     W, H, spp = p.width, p.height, p.samples
     p.strip_rows, p.strip_count, p.strip_index = STRIP_ROWS, world, rank
