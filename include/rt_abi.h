@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 4
+#define RT_ABI_VERSION 5
 
 /* ------------------------------------------------------------------ errors
  * 0 = Ok.  1..22 are exactly the reference's exit codes
@@ -276,11 +276,21 @@ enum RtArithmetic {
     RT_ARITH_FAST = 0,
     RT_ARITH_REFERENCE = 1
 };
+/* How rt_render_frame_multi_device collects this scene's strips in the output buffer.
+ *   RT_GATHER_AUTO (default): a scene on the output's device renders straight into the output; every other one
+ *     renders into its own frame and sends its strips by peer copies.
+ *   RT_GATHER_STAGED: this scene always takes the second road, also on the output's device — a switch for tests, so
+ *     that ONE card executes the staging + strided-copy code that several cards run.  Same frame either way. */
+enum RtGather {
+    RT_GATHER_AUTO = 0,
+    RT_GATHER_STAGED = 1
+};
 typedef struct RtSceneOptions {
     int32_t closest_hit; /* RtClosestHit  */
     int32_t kernel;      /* RtTraceKernel */
     int32_t arithmetic;  /* RtArithmetic  */
-    int32_t _reserved[5]; /* must be 0 */
+    int32_t gather;      /* RtGather      */
+    int32_t _reserved[4]; /* must be 0 */
 } RtSceneOptions;
 
 /* Statistics of the last render on a scene (path segments = ray_color
@@ -406,7 +416,7 @@ int rt_render_frame_rgba8(RtScene *scene, const RtCamera *camera, const RtRender
  *     its finished pixels over its own PCIe link into one pinned frame, which the
  *     call copies to out_rgb band by band while the devices render on;
  *   - rt_render_frame_multi_device: in out_rgb_device, memory of scenes[0]'s
- *     device, by peer copies over xGMI (one hipMemcpyPeerAsync per strip on the
+ *     device, by peer copies over xGMI (one strided copy per device on the
  *     SOURCE device's stream behind its resolve pass; a single process needs no
  *     RCCL rendezvous for that — the multi-PROCESS path gathers with RCCL,
  *     racer-tracer_amd/strips.py).  Synchronises before returning;

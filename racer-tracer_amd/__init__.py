@@ -117,15 +117,16 @@ class Scene:
     """RtScene handle: a scene uploaded to one GPU (rt_scene_create)."""
 
     def __init__(self, desc, device=0, closest_hit=abi.RT_HIT_AUTO, kernel=abi.RT_KERNEL_POOL, library=None,
-                 arithmetic=abi.RT_ARITH_FAST):
-        """closest_hit / kernel / arithmetic: RtSceneOptions (rt_scene_create_ex) — the defaults are
+                 arithmetic=abi.RT_ARITH_FAST, gather=abi.RT_GATHER_AUTO):
+        """closest_hit / kernel / arithmetic / gather: RtSceneOptions (rt_scene_create_ex) — the defaults are
         rt_scene_create's own; arithmetic=RT_ARITH_REFERENCE selects the reference's IEEE divisions without FMA
-        contraction.  library: load_library()."""
+        contraction; gather=RT_GATHER_STAGED makes rt_render_frame_multi_device stage and copy this scene's strips
+        even on the output's device.  library: load_library()."""
         self._lib = library or lib()
         self._h = C.c_void_p()
         self._desc_owner = desc  # keep SceneBundle / host session alive
         d = desc.desc if hasattr(desc, "desc") else desc
-        opt = abi.RtSceneOptions(closest_hit, kernel, arithmetic)
+        opt = abi.RtSceneOptions(closest_hit, kernel, arithmetic, gather)
         check(self._lib.rt_scene_create_ex(C.byref(d), device, C.byref(opt), C.byref(self._h)), "rt_scene_create_ex", self._lib)
         self.device = device
 

@@ -5,7 +5,7 @@ C header; tests/test_abi_layout.py checks the sizes against the C compiler.
 """
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # RtError (reference codes: racer-tracer/src/error.rs:71-97)
 RT_OK = 0
@@ -104,10 +104,12 @@ class RtToneMap(C.Structure):
 RT_HIT_AUTO, RT_HIT_LINEAR, RT_HIT_BVH = 0, 1, 2
 RT_KERNEL_POOL, RT_KERNEL_V1 = 0, 1
 RT_ARITH_FAST, RT_ARITH_REFERENCE = 0, 1
+RT_GATHER_AUTO, RT_GATHER_STAGED = 0, 1
 
 
 class RtSceneOptions(C.Structure):
-    _fields_ = [("closest_hit", C.c_int32), ("kernel", C.c_int32), ("arithmetic", C.c_int32), ("_reserved", C.c_int32 * 5)]
+    _fields_ = [("closest_hit", C.c_int32), ("kernel", C.c_int32), ("arithmetic", C.c_int32), ("gather", C.c_int32),
+                ("_reserved", C.c_int32 * 4)]
 
 
 RtTileCallback = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_int32,

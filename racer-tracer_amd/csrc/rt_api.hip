@@ -27,7 +27,7 @@
     extern "C" hipError_t rtdev_launch_trace_pool##SUFFIX(const rtdev::TraceArgs *args, int prims_class, int textured,    \
                                                           int specular, int bvh, unsigned blocks, hipStream_t stream);    \
     extern "C" hipError_t rtdev_launch_resolve_chunks##SUFFIX(const double *partial, double *out, int width, int height,  \
-                                                              int n_chunks, int strip_rows, int strip_count,              \
+                                                              int n_chunks, int slice_rows, int strip_rows, int strip_count, \
                                                               int strip_index, int step_x, int step_y, int cover_w,       \
                                                               int cover_h, int out_col_step, int out_cols, int samples,   \
                                                               hipStream_t stream);
@@ -368,7 +368,10 @@ int rtapi::enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderPara
             a.deliver_cols = delivery->cols;
         }
         const int n_batches = (int)plan.size();
-        if (s->partial.count < n * (size_t)total_chunks) RT_HIP(s->partial.alloc(n * (size_t)total_chunks));
+        // slices hold the launch's owned rows only (the kernel compacts rows: owned_rows, tile_py0)
+        a.slice_rows = a.owned_rows;
+        const size_t slice_elems = (size_t)p->width * (size_t)a.slice_rows * 3;
+        if (s->partial.count < slice_elems * (size_t)total_chunks) RT_HIP(s->partial.alloc(slice_elems * (size_t)total_chunks));
         if (s->queue.count < (size_t)n_batches) RT_HIP(s->queue.alloc((size_t)n_batches));
         a.partial = s->partial.ptr;
         RT_HIP(hipMemsetAsync(s->segments.ptr, 0, rtdev::RT_STAT_SLOTS * sizeof(unsigned long long), stream));
@@ -399,7 +402,7 @@ int rtapi::enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderPara
         }
         RT_HIP(hipEventRecord(s->ev_traced, stream));
         if (!delivery)
-            RT_HIP((s->exact ? rtdev_launch_resolve_chunks_exact : rtdev_launch_resolve_chunks)(s->partial.ptr, out_device, p->width, p->height, chunks_done, a.strip_rows,
+            RT_HIP((s->exact ? rtdev_launch_resolve_chunks_exact : rtdev_launch_resolve_chunks)(s->partial.ptr, out_device, p->width, p->height, chunks_done, a.slice_rows, a.strip_rows,
                                                a.strip_count, a.strip_index, a.step_x, a.step_y, a.cover_w, a.cover_h,
                                                out_col_step, out_cols, p->samples, stream));
         RT_HIP(hipEventRecord(s->ev_resolved, stream));
@@ -539,6 +542,7 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
     if (opt.closest_hit < RT_HIT_AUTO || opt.closest_hit > RT_HIT_BVH) return fail(RT_ERR_INVALID_ARGUMENT, "unknown closest_hit option");
     if (opt.kernel < RT_KERNEL_POOL || opt.kernel > RT_KERNEL_V1) return fail(RT_ERR_INVALID_ARGUMENT, "unknown kernel option");
     if (opt.arithmetic < RT_ARITH_FAST || opt.arithmetic > RT_ARITH_REFERENCE) return fail(RT_ERR_INVALID_ARGUMENT, "unknown arithmetic option");
+    if (opt.gather < RT_GATHER_AUTO || opt.gather > RT_GATHER_STAGED) return fail(RT_ERR_INVALID_ARGUMENT, "unknown gather option");
     for (int32_t r : opt._reserved)
         if (r != 0) return fail(RT_ERR_INVALID_ARGUMENT, "reserved option fields must be 0");
     int n_dev = rt_device_count();
@@ -550,6 +554,7 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
     if (!s) return fail(RT_ERR_OUT_OF_MEMORY, "host allocation failed");
     s->device = device;
     s->exact = opt.arithmetic == RT_ARITH_REFERENCE;
+    s->gather_staged = opt.gather == RT_GATHER_STAGED;
     struct Guard { // destroy the half-built scene on any early return
         RtScene *s;
         ~Guard() { if (s) rt_scene_destroy(s); }

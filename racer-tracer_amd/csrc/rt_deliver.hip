@@ -141,6 +141,10 @@ int make_shares(RtScene *const *scenes, int n, const RtRenderParams *p, int stri
 
 int launch_shares(std::vector<Share> &shares, const RtCamera *camera) {
     for (Share &sh : shares) {
+        // A share that owns no rows (more shares than strips: height 16 over three scenes; a strip_index whose first
+        // strip lies below the image) has nothing to launch and nothing to wait for: it counts as published, and the
+        // rows of the frame stay as they are — what the two-pass path does with n_items == 0.
+        if (sh.delivery.regions.empty()) continue;
         sh.delivery.serial = ++sh.scene->deliver_serial;
         if (sh.delivery.serial == 0) sh.delivery.serial = ++sh.scene->deliver_serial; // 0 is the flags' idle value
         const int rc = rtapi::enqueue_render(sh.scene, camera, &sh.params, nullptr, sh.scene->stream, 0, Cancel(), &sh.delivery);
@@ -280,7 +284,7 @@ int deliver_tiles(RtScene *const *scenes, int n, const RtCamera *camera, const R
     columns_after.back() = p->tiles_w;
     for (Share &sh : shares) {
         const int tile_rows = (rtapi::owned_rows_of(&sh.params) + 7) / 8;
-        sh.delivery.regions = regions;
+        if (tile_rows > 0) sh.delivery.regions = regions; // (none: the share owns no rows and is not launched)
         for (rtdev::Region &reg : sh.delivery.regions) reg.nty = tile_rows;
         sh.delivery.out = scenes[0]->host_frame;
         sh.delivery.col_step = width_step;
@@ -291,6 +295,7 @@ int deliver_tiles(RtScene *const *scenes, int n, const RtCamera *camera, const R
     int emitted = 0;
     for (size_t r = 0; r < regions.size() && rc == RT_OK && !cancelled; ++r) {
         for (Share &sh : shares) {
+            if (!sh.launched) continue; // owns no rows
             rc = wait_region(sh, (int)r, cancel);
             if (rc != RT_OK) break;
         }

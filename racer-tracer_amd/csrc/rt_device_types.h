@@ -161,7 +161,8 @@ struct TraceArgs {
     // chunk-major: item = chunk * n_tiles + tile.  Each item writes the sums of
     // its samples to partial[chunk_base + chunk][pixel]; k_resolve adds the
     // chunks in index order, so the result does not depend on scheduling.
-    double *partial;             // [n_chunks_total][height][width][3]
+    double *partial;             // [n_chunks_total][slice_rows][width][3]: the rows of the launch's OWNED-row grid only
+    int32_t slice_rows;          // rows per slice = owned_rows (a rank's eighth of a C5 frame keeps 0.53 GB of slices, not 4.2)
     unsigned int *queue;         // item counter (zeroed before the launch)
     uint32_t n_items;
     int32_t n_chunks;            // chunks in this launch

@@ -6,8 +6,8 @@
 // the shards are 8-row strips, strip j -> scenes[j % n] (interleaved: cheap sky
 // rows and expensive floor rows spread evenly), every device traces its strips
 // on its own stream at the same time, and the finished strips are collected
-// in device 0's HBM by peer copies over xGMI, enqueued on the SOURCE device's
-// stream right behind its resolve pass.
+// in device 0's HBM by peer copies over xGMI — one strided copy per device —
+// enqueued on the SOURCE device's stream right behind its resolve pass.
 // One process owns every device here, so plain peer copies (SDMA engines over
 // the xGMI links) do the gather; RCCL's rendezvous buys nothing without a
 // second process.  The multi-process form of the same gather is
@@ -72,7 +72,9 @@ int render_multi(RtScene *const *scenes, int n, const RtCamera *camera, const Rt
             sh.params.strip_index = i;
         }
         RT_HIP(hipSetDevice(sh.scene->device));
-        sh.in_place = sh.scene->device == dst_device;
+        // RT_GATHER_STAGED (RtSceneOptions.gather, a test switch): the share renders into its own staging frame and is
+        // copied even when it sits on the output's device, so that ONE card runs what several run
+        sh.in_place = sh.scene->device == dst_device && !sh.scene->gather_staged;
         if (sh.in_place) {
             sh.target = out;
         } else {
@@ -87,7 +89,7 @@ int render_multi(RtScene *const *scenes, int n, const RtCamera *camera, const Rt
     if (n > 1) {
         for (int i = 0; i < n; ++i) {
             const int dev = scenes[i]->device;
-            if (dev == dst_device) continue;
+            if (dev == dst_device) continue; // (a staged share on the output's device copies within the device)
             RT_HIP(hipSetDevice(dev));
             int can = 0;
             RT_HIP(hipDeviceCanAccessPeer(&can, dev, dst_device));
@@ -107,22 +109,40 @@ int render_multi(RtScene *const *scenes, int n, const RtCamera *camera, const Rt
             first_error = fail(RT_ERR_HIP, "hipSetDevice failed");
             break;
         }
-        for (int j = (n > 1 ? i : 0); j < n_strips; j += (n > 1 ? n : 1)) {
-            const int r0 = j * strip_rows;
-            const int rows = (r0 + strip_rows <= p->height ? strip_rows : p->height - r0) ;
-            const size_t off = (size_t)r0 * row_elems, bytes = (size_t)rows * row_elems * sizeof(double);
-            hipError_t e;
-            if (n == 1) { // one share (on another device than the output): the whole frame in one copy
-                e = hipMemcpyPeerAsync(out, dst_device, sh.target, sh.scene->device, n_elems * sizeof(double), sh.scene->stream);
-                j = n_strips;
-            } else {
-                e = hipMemcpyPeerAsync(out + off, dst_device, sh.target + off, sh.scene->device, bytes, sh.scene->stream);
+        const int src_device = sh.scene->device;
+        hipStream_t st = sh.scene->stream;
+        auto peer = [&](size_t off_elems, size_t bytes) {
+            return bytes == 0 ? hipSuccess : hipMemcpyPeerAsync(out + off_elems, dst_device, sh.target + off_elems, src_device, bytes, st);
+        };
+        hipError_t e = hipSuccess;
+        if (n == 1) { // one share (on another device than the output, or staged): the whole frame in one copy
+            e = peer(0, n_elems * sizeof(double));
+        } else {
+            // Share i owns the strips i, i + n, i + 2n, ...: `full` whole strips, pitch n * strip_rows rows apart — ONE
+            // strided copy (34 strips per device at C5) — and possibly one short strip at the bottom of the image.
+            const size_t strip_bytes = (size_t)strip_rows * row_elems * sizeof(double);
+            const size_t pitch = strip_bytes * (size_t)n;
+            int full = 0, tail_rows = 0, tail_row0 = 0;
+            for (int j = i; j < n_strips; j += n) {
+                const int r0 = j * strip_rows;
+                if (r0 + strip_rows <= p->height) ++full;
+                else {
+                    tail_rows = p->height - r0;
+                    tail_row0 = r0;
+                }
             }
-            if (e != hipSuccess) {
-                first_error = fail(RT_ERR_HIP, std::string("strip copy: ") + hipGetErrorString(e));
-                break;
+            const size_t first = (size_t)i * (size_t)strip_rows * row_elems;
+            if (full > 0) {
+                e = hipMemcpy2DAsync(out + first, pitch, sh.target + first, pitch, strip_bytes, (size_t)full, hipMemcpyDeviceToDevice, st);
+                if (e != hipSuccess) { // a runtime that refuses a strided copy between these two devices: strip by strip
+                    (void)hipGetLastError();
+                    e = hipSuccess;
+                    for (int k = 0; k < full && e == hipSuccess; ++k) e = peer(first + (size_t)k * (pitch / sizeof(double)), strip_bytes);
+                }
             }
+            if (e == hipSuccess && tail_rows > 0) e = peer((size_t)tail_row0 * row_elems, (size_t)tail_rows * row_elems * sizeof(double));
         }
+        if (e != hipSuccess) first_error = fail(RT_ERR_HIP, std::string("strip copy: ") + hipGetErrorString(e));
     }
     // 3. the frame is complete when every stream has drained
     for (int i = 0; i < n; ++i) {

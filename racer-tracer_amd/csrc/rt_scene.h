@@ -88,6 +88,7 @@ struct RtScene {
     // pooled kernel (default): persistent grid = CUs x resident blocks of the variant
     bool use_v1 = false;   // RtSceneOptions.kernel == RT_KERNEL_V1: the lane-per-pixel kernel
     bool exact = false;    // RtSceneOptions.arithmetic == RT_ARITH_REFERENCE: the *_exact copy of the trace kernels
+    bool gather_staged = false; // RtSceneOptions.gather == RT_GATHER_STAGED (rt_multi.hip)
     int num_cus = 0, pool_blocks_per_cu = 1;
     int pool_blocks_per_cu_lens = 1; // ... when the camera has an aperture (its lens samples take dynamic LDS)
     rtapi::DevBuf<double> partial;       // [chunks][H][W][3] per-chunk sums

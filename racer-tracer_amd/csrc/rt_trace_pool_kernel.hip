@@ -365,7 +365,7 @@ __device__ __noinline__ void deliver_item(const RT_CONSTANT TraceArgs *K_in, dou
     region = __builtin_amdgcn_readfirstlane(region);
     reg_tiles = (uint32_t)__builtin_amdgcn_readfirstlane((int)reg_tiles);
     {
-        const size_t slice = (size_t)K->height * (size_t)K->width * 3;
+        const size_t slice = (size_t)K->slice_rows * (size_t)K->width * 3; // a slice holds the launch's owned rows only
         // (pixel coordinates are formed again here rather than kept in registers across the path loop)
         const int out_px = (tx * 8 + (lane & 7)) * K->step_x;
         int out_py = tile_py0 + (lane >> 3) * K->step_y;
@@ -373,7 +373,8 @@ __device__ __noinline__ void deliver_item(const RT_CONSTANT TraceArgs *K_in, dou
             const int vrow = ty * 8 + (lane >> 3);
             out_py = ((vrow / K->strip_rows) * K->strip_count + K->strip_index) * K->strip_rows + vrow % K->strip_rows;
         }
-        double *dst = K->partial + (size_t)(K->chunk_base + chunk) * slice + ((size_t)out_py * (size_t)K->width + (size_t)out_px) * 3;
+        const size_t in_slice = ((size_t)(ty * 8 + (lane >> 3)) * (size_t)K->width + (size_t)out_px) * 3;
+        double *dst = K->partial + (size_t)(K->chunk_base + chunk) * slice + in_slice;
         // ---- DELIVERY: the launch finishes its own pixels (rt_device_types.h: TraceArgs.deliver_out).
         // The slices cross waves inside ONE launch here, and an XCD's L2 is not coherent with its seven neighbours':
         // a device-scope release fence per item (L2 write-back + invalidate) was measured first and costs C2 12 %
@@ -394,7 +395,7 @@ __device__ __noinline__ void deliver_item(const RT_CONSTANT TraceArgs *K_in, dou
         // Every chunk of this tile has landed: vec3.rs:119-125 scale_sqrt over the slices in chunk order —
         // exactly k_resolve_chunks_f64's sum, so the pixels are bit-identical to the two-pass path.
         if (my_valid) {
-            const double *src = K->partial + ((size_t)out_py * (size_t)K->width + (size_t)out_px) * 3;
+            const double *src = K->partial + in_slice;
             double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
 #pragma unroll 1
             for (int c = 0; c < K->total_chunks; ++c) {
@@ -949,7 +950,9 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
         // ---- item done: its sums go to its own slice of `partial`
         if (A.deliver_out == nullptr) {
             if (my_valid) {
-                double *dst = A.partial + ((size_t)(A.chunk_base + (int)chunk) * (size_t)A.height * (size_t)A.width + (size_t)my_pixel) * 3;
+                // slice row = row of the launch's owned-row grid (a share's slices hold its own rows only)
+                const size_t in_slice = (size_t)(ty * 8 + (lane >> 3)) * (size_t)A.width + (size_t)((tx * 8 + (lane & 7)) * A.step_x);
+                double *dst = A.partial + ((size_t)(A.chunk_base + (int)chunk) * (size_t)A.slice_rows * (size_t)A.width + in_slice) * 3;
                 dst[0] = L.sum[lane][0];
                 dst[1] = L.sum[lane][1];
                 dst[2] = L.sum[lane][2];
@@ -978,32 +981,41 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
 // of the tile stream — column c of out_col_step pixels (the last takes the remainder, cpu.rs:97-109) stored as
 // [height][column width][3] behind the columns before it — so that a tile of rt_render is one contiguous run.
 __global__ __launch_bounds__(256) void k_resolve_chunks_f64(const double *__restrict__ partial, double *__restrict__ out,
-                                                            int width, int height, int n_chunks, int strip_rows,
+                                                            int width, int height, int n_chunks, int slice_rows, int strip_rows,
                                                             int strip_count, int strip_index, int step_x, int step_y,
                                                             int cover_w, int cover_h, int out_col_step, int out_cols,
                                                             double scale) {
-    const size_t n = (size_t)width * (size_t)height * 3;
+    // a slice holds the launch's OWNED rows only (TraceArgs.slice_rows): with strips the pass walks those rows and maps
+    // each to its image row; the preview's slice rows are grid rows, read by every pixel of a block
+    const size_t slice = (size_t)width * (size_t)slice_rows * 3;
+    const size_t n = (size_t)width * (size_t)(strip_count > 1 ? slice_rows : height) * 3;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         size_t src = i, dst = i;
         if (strip_count > 1 || step_x > 1 || step_y > 1 || out_cols > 1) {
             const size_t pixel = i / 3;
-            const int row = (int)(pixel / (size_t)width), col = (int)(pixel - (size_t)row * (size_t)width);
-            if (strip_count > 1 && (row / strip_rows) % strip_count != strip_index) continue;
+            const int ch = (int)(i - pixel * 3);
+            const int r = (int)(pixel / (size_t)width), col = (int)(pixel - (size_t)r * (size_t)width);
+            int row = r;
+            if (strip_count > 1) { // r is a row of the owned-row grid
+                row = ((r / strip_rows) * strip_count + strip_index) * strip_rows + r % strip_rows;
+                if (row >= height) continue;
+            }
+            dst = ((size_t)row * (size_t)width + (size_t)col) * 3 + ch;
             if (out_cols > 1) {
                 int c = col / out_col_step;
                 if (c > out_cols - 1) c = out_cols - 1;
                 const int col_x = c * out_col_step;
                 const int col_w = c == out_cols - 1 ? width - col_x : out_col_step;
-                dst = ((size_t)height * (size_t)col_x + (size_t)row * (size_t)col_w + (size_t)(col - col_x)) * 3 + (i - pixel * 3);
+                dst = ((size_t)height * (size_t)col_x + (size_t)row * (size_t)col_w + (size_t)(col - col_x)) * 3 + ch;
             }
             if (col >= cover_w || row >= cover_h) {
                 out[dst] = 0.0;
                 continue;
             }
-            src = ((size_t)(row - row % step_y) * (size_t)width + (size_t)(col - col % step_x)) * 3 + (i - pixel * 3);
+            src = ((size_t)(r / step_y) * (size_t)width + (size_t)(col - col % step_x)) * 3 + ch;
         }
         double acc = 0.0;
-        for (int c = 0; c < n_chunks; ++c) acc += partial[(size_t)c * n + src];
+        for (int c = 0; c < n_chunks; ++c) acc += partial[(size_t)c * slice + src];
         out[dst] = sqrt(scale * acc);
     }
 }
@@ -1060,19 +1072,19 @@ extern "C" hipError_t RT_LAUNCHER(rtdev_launch_trace_pool)(const rtdev::TraceArg
 }
 
 extern "C" hipError_t RT_LAUNCHER(rtdev_launch_resolve_chunks)(const double *partial, double *out, int width, int height, int n_chunks,
-                                                               int strip_rows, int strip_count, int strip_index, int step_x, int step_y,
+                                                               int slice_rows, int strip_rows, int strip_count, int strip_index, int step_x, int step_y,
                                                                int cover_w, int cover_h, int out_col_step, int out_cols, int samples,
                                                                hipStream_t stream) {
     if (out_cols <= 1 || out_col_step <= 0) {
         out_cols = 1;
         out_col_step = width;
     }
-    size_t n = (size_t)width * (size_t)height * 3;
+    size_t n = (size_t)width * (size_t)(strip_count > 1 ? slice_rows : height) * 3;
     unsigned blocks = (unsigned)((n + 255) / 256);
     if (blocks > 4096u) blocks = 4096u;
     if (blocks == 0) return hipSuccess;
     hipLaunchKernelGGL(RT_KNS::k_resolve_chunks_f64, dim3(blocks), dim3(256), 0, stream, partial, out, width, height,
-                       n_chunks, strip_rows, strip_count, strip_index, step_x, step_y, cover_w, cover_h, out_col_step, out_cols,
+                       n_chunks, slice_rows, strip_rows, strip_count, strip_index, step_x, step_y, cover_w, cover_h, out_col_step, out_cols,
                        1.0 / (double)samples);
     return hipGetLastError();
 }

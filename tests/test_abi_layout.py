@@ -35,7 +35,7 @@ def test_python_prototypes_cover_the_headers(rt):
 
 
 def test_abi_version_and_strerror(rt):
-    assert rt.lib().rt_abi_version() == rt.abi.ABI_VERSION == 4
+    assert rt.lib().rt_abi_version() == rt.abi.ABI_VERSION == 5
     # error.rs:71-97 numbering
     for code, text in ((0, "Ok"), (4, "Unknown Material"), (7, "Cancel event"), (9, "Scene failed to load"),
                        (21, "Failed to open image"), (100, "No usable HIP device")):

@@ -208,6 +208,38 @@ def test_whole_frame_over_several_scenes_matches(rt, gpu):
             s.close()
 
 
+def test_shares_that_own_no_rows(rt, gpu):
+    """More shares than 8-row strips (height 16 over three scenes), or a strip_index whose first strip lies below the
+    image: such a share launches nothing and counts as published; the call succeeds, the other rows are complete and
+    the share's (non-existent) rows of the caller's buffer stay untouched — what the two-pass path does with zero work
+    items."""
+    bundle, cam, _ = S.cornell_box()
+    w, h, spp = 64, 16, 12
+    camera = S.camera_for(cam, w, h)
+    params = S.abi.render_params(w, h, spp, tiles_w=4, tiles_h=2)
+    scenes = [rt.Scene(bundle) for _ in range(4)]
+    try:
+        want = two_pass_frame(scenes[0], camera, params)
+        want_tiles = scenes[0].render_tiles(camera, params)
+        for n in (3, 4):                                             # 2 strips: shares 2 and 3 own nothing
+            assert np.array_equal(rt.render_frame_multi(scenes[:n], camera, params), want)
+            tiles = rt.render_tiles_multi(scenes[:n], camera, params)
+            assert [t[:4] for t in tiles] == [t[:4] for t in want_tiles]
+            for got, ref in zip(tiles, want_tiles):
+                assert np.array_equal(got[4], ref[4])
+            assert [int(s.last_stats().samples) for s in scenes[:2]] == [w * 8 * spp] * 2
+        # one scene, a strip index beyond the image: RT_OK, nothing written (render_frame hands in a zeroed buffer)
+        for idx in (2, 4):
+            p = S.abi.render_params(w, h, spp, strip_rows=8, strip_count=5, strip_index=idx)
+            assert (scenes[0].render_frame(camera, p) == 0).all()
+        p = S.abi.render_params(w, h, spp, strip_rows=8, strip_count=5, strip_index=1)
+        part = scenes[0].render_frame(camera, p)                     # ... and the scene still renders afterwards
+        assert np.array_equal(part[8:], want[8:]) and (part[:8] == 0).all()
+    finally:
+        for s in scenes:
+            s.close()
+
+
 def test_paths_that_do_not_deliver_still_stream_tiles(rt, gpu):
     """The v1 kernel and the preview scale render with the two-pass path and cut the tiles from the finished frame
     (rt_deliver.hip: tiles_from_frame): same tiles, the cancel callback honoured; several devices refuse them."""

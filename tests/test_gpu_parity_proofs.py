@@ -252,6 +252,48 @@ def test_multi_device_call_into_device_memory(rt, gpu):
             s.close()
 
 
+def test_staged_gather_runs_the_peer_copy_branch_on_one_card(rt, gpu):
+    """rt_render_frame_multi_device with RtSceneOptions.gather = RT_GATHER_STAGED: every share renders into its OWN
+    frame and its strips travel by the strided copy (+ the copy of a short last strip) that several devices use —
+    csrc/rt_multi.hip step 2, which a one-GPU box never reaches otherwise because a share on the output's device renders
+    in place.  2 and 3 shares, strips of 8 and 5 rows, 131 rows (a short last strip), one staged share alone, a mix
+    of staged and in-place shares: the output must equal the single-scene frame (cpu.rs:118-131 shards ONE frame)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU (the library does): no way to allocate the device buffer for this test")
+    bundle, cam, _ = S.cornell_box_boxes()
+    w, h, spp = 200, 131, 16
+    camera = S.camera_for(cam, w, h)
+    params = S.abi.render_params(w, h, spp)
+    staged = [rt.Scene(bundle, gather=S.abi.RT_GATHER_STAGED) for _ in range(3)]
+    plain = [rt.Scene(bundle) for _ in range(3)]
+
+    def multi_device(scenes, strip_rows):
+        out = torch.full((h, w, 3), -1.0, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        rt.render_frame_multi_device(scenes, camera, params, out.data_ptr(), strip_rows)
+        return out.cpu().numpy()
+
+    try:
+        whole = plain[0].render_frame(camera, params)
+        for n, strip_rows in ((1, 0), (2, 0), (3, 8), (2, 16), (3, 5), (2, 5), (3, 24)):
+            got = multi_device(staged[:n], strip_rows)
+            assert (got != -1.0).all(), (n, strip_rows)               # every row arrived
+            in_place = multi_device(plain[:n], strip_rows)
+            assert np.array_equal(got, in_place), (n, strip_rows)     # same kernel work, another road to the output
+            if strip_rows % 8 == 0:
+                assert np.array_equal(got, whole), (n, strip_rows)
+            else:
+                assert np.abs(got - whole).max() < 1e-12, (n, strip_rows)
+        mixed = multi_device([plain[0], staged[1], staged[2]], 8)      # share 0 in place, 1 and 2 copied
+        assert np.array_equal(mixed, whole)
+        # more shares than strips: shares 2.. own nothing (h = 131, strips of 64 rows: 3 strips for 3 shares, of 128: 2)
+        assert np.array_equal(multi_device(staged, 128), whole)
+    finally:
+        for s in staged + plain:
+            s.close()
+
+
 def test_device_counted_samples_follow_the_work(rt, gpu):
     """RtRenderStats.samples is counted on the device, where a path is handed out: strips, column windows
     of the tile stream and the preview grid all report what they really traced."""

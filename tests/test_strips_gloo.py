@@ -64,6 +64,48 @@ def test_two_rank_gather_equals_single_rank_frame(tmp_path, orc, world, h, rows,
     assert np.array_equal(got, full)
 
 
+def _pattern(h, w):
+    """A frame whose every element names its own (row, column, channel)."""
+    r = torch.arange(h, dtype=torch.float64).view(h, 1, 1)
+    c = torch.arange(w, dtype=torch.float64).view(1, w, 1)
+    k = torch.arange(3, dtype=torch.float64).view(1, 1, 3)
+    return r * 4096.0 + c + k * 0.25
+
+
+def _pattern_worker(rank, world, port, w, h, rows, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    strips = importlib.import_module("racer-tracer_amd.strips")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = strips.StripGather(h, w, rows, world, rank, "cpu", dist)
+        frame = g.frame()                       # bench.py's way: render into the gather's own staging buffer
+        own = g.owned_row_mask()
+        frame[own] = _pattern(h, w)[own]        # this rank's strips only; everything else stays zero
+        assert int(own.sum()) == sum(min(rows, h - j * rows) for j in g.owned())
+        g.gather(frame)
+        dist.barrier()
+        if rank == 0:
+            np.save(out_path, frame.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,w,h,rows", [(8, 1920, 1080, 8),    # the bench frame: 135 strips over 8 ranks, 17 slots each, one padded
+                                            (8, 64, 2160, 8),      # BASELINE config 5's rows: 270 strips, 34 slots, two padded
+                                            (4, 1920, 1080, 8),    # 135 over 4: three ranks own 34 strips, one owns 33
+                                            (8, 48, 1083, 8)])     # a short last strip (3 rows) on top of the padding
+def test_gather_padding_at_real_frame_sizes(tmp_path, world, w, h, rows):
+    """StripGather pads every rank to the same number of strip slots when n_strips % world != 0.  The render tests above
+    cover it at heights of 22-50 rows; this is the gather ALONE at the sizes bench.py --gpus 8 and config 5 run it
+    (cpu.rs:118-131 collects tiles of the real frame), with a frame whose every element names its own position, so a
+    strip that lands in the wrong slot, a padded slot that leaks into the frame or a truncated last strip shows."""
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_pattern_worker, args=(world, _free_port(), w, h, rows, out), nprocs=world, join=True)
+    assert np.array_equal(np.load(out), _pattern(h, w).numpy())
+
+
 def test_strip_gather_single_rank_is_a_no_op():
     strips = importlib.import_module("racer-tracer_amd.strips")
     g = strips.StripGather(20, 6, 8, 1, 0, "cpu")
