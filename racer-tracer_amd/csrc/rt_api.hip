@@ -259,6 +259,7 @@ void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtd
     a.leaf_inv_dt = s->leaf_inv_dt;
     for (int g = 0; g < 3; ++g) a.rect_end[g] = s->rect_end[g];
     a.sphere_end = s->sphere_end;
+    a.box_end = s->box_end;
 #ifdef RT_DEVELOPER_KNOBS // throw-away kernel knobs of the developer build (tools/perf_ab.sh)
     for (int k = 0; k < 4; ++k) {
         char name[16];
@@ -571,6 +572,12 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
         for (int k = 0; k < 3; ++k) q.tr[k] = p.translate[k];
         q.kind = p.kind;
         q.flags = p.flags & (RT_PRIM_HAS_ROTATE_Y | RT_PRIM_HAS_TRANSLATE);
+        // an absent wrapper is the identity on the device (box_t subtracts the offset unconditionally)
+        if (!(q.flags & RT_PRIM_HAS_TRANSLATE)) q.tr[0] = q.tr[1] = q.tr[2] = 0.0;
+        if (!(q.flags & RT_PRIM_HAS_ROTATE_Y)) {
+            q.rot_sin = 0.0;
+            q.rot_cos = 1.0;
+        }
         q.material = p.material;
         q.inv_radius = (p.kind == RT_PRIM_SPHERE || p.kind == RT_PRIM_MOVING_SPHERE) ? 1.0 / p.p[3] : 0.0;
         q.radius2 = p.p[3] * p.p[3];
@@ -669,13 +676,15 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
             if (q.flags == 0 && q.kind == RT_PRIM_XZ_RECT) return 1;
             if (q.flags == 0 && q.kind == RT_PRIM_YZ_RECT) return 2;
             if (q.flags == 0 && q.kind == RT_PRIM_SPHERE) return 3;
-            return 4;
+            if (q.kind == RT_PRIM_BOX) return 4; // bare or wrapped
+            return 5;
         };
-        for (int g = 0; g < 5; ++g) {
+        for (int g = 0; g < 6; ++g) {
             for (const rtdev::Prim &q : prims)
                 if (group_of(q) == g) sorted.push_back(q);
             if (g < 3) s->rect_end[g] = (int)sorted.size();
             if (g == 3) s->sphere_end = (int)sorted.size();
+            if (g == 4) s->box_end = (int)sorted.size();
         }
         prims.swap(sorted);
     }

@@ -207,11 +207,12 @@ struct TraceArgs {
     const LeafGeo *leaf_geo;             // per primitive of the (leaf-ordered) table
     double leaf_time_a, leaf_inv_dt;     // MovingSphere.time_a and 1 / (time_b - time_a) of the tag-0 records
     // Linear-loop variants: the device table is grouped — untransformed XY rects first, then XZ, then YZ
-    // (rect_end[a] is the end of group a), then untransformed spheres (sphere_end), then everything else
-    // (boxes, moving spheres, wrapped primitives) — so that the closest-hit loop runs one straight-line test
-    // per group instead of a scalar switch on the kind of every record.
+    // (rect_end[a] is the end of group a), then untransformed spheres (sphere_end), then boxes with or without
+    // wrappers (box_end), then everything else (moving spheres, wrapped rects and spheres) — so that the
+    // closest-hit loop runs one straight-line test per group instead of a scalar switch on the kind of every record.
     int32_t rect_end[3];
     int32_t sphere_end;
+    int32_t box_end;
     int32_t lens_lds;      // the camera has an aperture: the lens-disk samples of the batches sit at the end of dynamic LDS
     int32_t dbg[4];        // developer knobs (env RT_DBG0..3), 0 in production
 };

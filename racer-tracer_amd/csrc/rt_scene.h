@@ -72,6 +72,7 @@ struct RtScene {
     int prims_class = 2;
     int rect_end[3] = {0, 0, 0}; // linear loop: ends of the XY / XZ / YZ rect groups of the (grouped) device table
     int sphere_end = 0;          // ... and of the plain-sphere group behind them
+    int box_end = 0;             // ... and of the boxes (wrapped or not) behind those
     int textured = 0; // some material's texture is not a plain SolidColor
     int specular = 0; // some material is Metal or Dielectric
 

@@ -321,6 +321,47 @@ __device__ __forceinline__ bool sphere_t(d3 center, double radius2, d3 o, d3 d, 
     return true;
 }
 
+// box.rs:82-101 — a Boxx is a list of six rects (box.rs:22-71), hit() keeps the side with the smallest t in
+// [t_min, t_max] whose in-plane point lies inside the rect's inclusive bounds.  For an axis-aligned box those six tests
+// are the three-slab test read twice: the ray is inside the slab pair of axis a for t between its two plane distances,
+// inside the box for t in [t_enter, t_exit] = [max of the three nearer, min of the three farther], and the side
+// hit() returns is the entry side when t_enter lies in the range, else the exit side (origin inside the box, or closer
+// than t_min in front of it).  The six plane distances are the rect tests' own (k - o) / d, so a hit's t is the value
+// the six-rect form returns, bit for bit; what differs is how "inside the rect" is decided for rays that graze an edge
+// of the box to within rounding: by comparing plane distances here, by comparing the in-plane point with the bounds
+// there (ties and such grazing rays are open, SURVEY B-15).  12 subtract/multiplies, 10 min/max and the side code
+// instead of six rects of 10 vector instructions and a select chain each.
+// `side` = box.rs's side index (box_side above): 2 * (2 - axis) + (the plane at box_min ? 1 : 0).
+// The RT_ARITH_REFERENCE kernels keep the six rect tests (the reference's own comparisons).
+__device__ __forceinline__ bool box_slab_t(const double *p, d3 o, d3 d, d3 inv_d, double t_min, double t_max, double &t_out,
+                                           int &side) {
+    const double x_mn = div_by(p[0] - o.x, d.x, inv_d.x), x_mx = div_by(p[3] - o.x, d.x, inv_d.x);
+    const double y_mn = div_by(p[1] - o.y, d.y, inv_d.y), y_mx = div_by(p[4] - o.y, d.y, inv_d.y);
+    const double z_mn = div_by(p[2] - o.z, d.z, inv_d.z), z_mx = div_by(p[5] - o.z, d.z, inv_d.z);
+    // (fmin / fmax drop a NaN — 0 * inf, origin exactly on a plane of a slab the ray runs parallel to — like the root
+    // clip of the BVH walk: the slab then constrains nothing, as for the rect tests, whose NaN comparisons all fail)
+    const double x_near = fmin(x_mn, x_mx), x_far = fmax(x_mn, x_mx);
+    const double y_near = fmin(y_mn, y_mx), y_far = fmax(y_mn, y_mx);
+    const double z_near = fmin(z_mn, z_mx), z_far = fmax(z_mn, z_mx);
+    const double t_enter = fmax(fmax(x_near, y_near), z_near);
+    const double t_exit = fmin(fmin(x_far, y_far), z_far);
+    const bool entry = t_enter >= t_min;
+    const double t = entry ? t_enter : t_exit;
+    // which of the six planes t is: the axis whose near (far) distance it equals, and there the plane at box_min when
+    // that is the nearer (farther) one
+    int axis, at_min;
+    if (entry) {
+        axis = t == z_near ? 2 : (t == y_near ? 1 : 0);
+        at_min = axis == 2 ? z_mn <= z_mx : (axis == 1 ? y_mn <= y_mx : x_mn <= x_mx);
+    } else {
+        axis = t == z_far ? 2 : (t == y_far ? 1 : 0);
+        at_min = axis == 2 ? z_mn >= z_mx : (axis == 1 ? y_mn >= y_mx : x_mn >= x_mx);
+    }
+    side = 2 * (2 - axis) + at_min;
+    t_out = t;
+    return t_enter <= t_exit && t >= t_min && t <= t_max;
+}
+
 // Nearest t of primitive P in [t_min, t_max], wrappers applied
 // (translate.rs:31, rotate_y.rs:39-48).  aux = box side.
 template <int PRIMS>
@@ -340,7 +381,8 @@ __device__ __forceinline__ bool prim_t(const Prim &P, d3 o, d3 d, d3 inv_d, doub
         if (P.flags & RT_PRIM_HAS_ROTATE_Y) {
             o = rot_fwd(o, P.rot_sin, P.rot_cos);
             d = rot_fwd(d, P.rot_sin, P.rot_cos);
-            inv_d = rcp3(d); // the rotation preserves |d|, so inv_a stands
+            inv_d.x = rcp_f64(d.x); // (d.y is untouched, and the rotation preserves |d|, so inv_a stands)
+            inv_d.z = rcp_f64(d.z);
         }
     }
     switch (PRIMS == PRIMS_SPHERES ? (int)RT_PRIM_SPHERE : P.kind) {
@@ -355,6 +397,9 @@ __device__ __forceinline__ bool prim_t(const Prim &P, d3 o, d3 d, d3 inv_d, doub
     case RT_PRIM_XZ_RECT: return rect_t<true>(1, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, t_min, t_max, t_out);
     case RT_PRIM_YZ_RECT: return rect_t<true>(0, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, t_min, t_max, t_out);
     default: { // box.rs:82-101
+#ifndef RT_EXACT_DIV
+        return box_slab_t(P.p, o, d, inv_d, t_min, t_max, t_out, aux);
+#endif
         bool any = false;
         double closest = t_max;
 #pragma unroll
@@ -372,6 +417,25 @@ __device__ __forceinline__ bool prim_t(const Prim &P, d3 o, d3 d, d3 inv_d, doub
         return any;
     }
     }
+}
+
+// A record of the linear loop's BOX group (TraceArgs.box_end): a Boxx, bare or inside RotateY and / or Translate
+// (translate.rs:31, rotate_y.rs:39-48; the YAML loader's only wrapped objects in the shipped scenes, sandbox.rs:39-80).
+// The record is wave-uniform: its flags steer scalar branches, sin / cos / offset and the six bounds are SGPR operands.
+// The ray is moved into the box's frame once (an unwrapped box's offset is (0, 0, 0): o - 0 is o), not once per side.
+__device__ __forceinline__ bool box_t(const Prim &P, d3 o, d3 d, d3 inv_d, double t_min, double t_max, double &t_out, int &side) {
+#ifdef RT_EXACT_DIV
+    return prim_t<PRIMS_ANY>(P, o, d, inv_d, 0.0, 0.0, t_min, t_max, t_out, side);
+#else
+    o = o - ld3(P.tr);
+    if (P.flags & RT_PRIM_HAS_ROTATE_Y) {
+        o = rot_fwd(o, P.rot_sin, P.rot_cos);
+        d = rot_fwd(d, P.rot_sin, P.rot_cos);
+        inv_d.x = rcp_f64(d.x);
+        inv_d.z = rcp_f64(d.z);
+    }
+    return box_slab_t(P.p, o, d, inv_d, t_min, t_max, t_out, side);
+#endif
 }
 
 // Closest hit through the skip-link BVH (rt_bvh.h): one integer of traversal

@@ -779,7 +779,16 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                                         best_aux = 0;
                                     }
                                 }
-                                for (; i < A.n_prims; ++i) test(load_prim_uniform(A.prims, i), i); // boxes, moving spheres, wrapped primitives
+                                for (; i < KB->box_end; ++i) { // boxes, bare or wrapped: box.rs:82-101 as three slabs, no switch
+                                    double t;
+                                    int side;
+                                    if (box_t(load_prim_uniform(A.prims, i), o, d, inv_d, 0.001, best_t, t, side)) {
+                                        best_t = t;
+                                        best = i;
+                                        best_aux = side;
+                                    }
+                                }
+                                for (; i < A.n_prims; ++i) test(load_prim_uniform(A.prims, i), i); // moving spheres, wrapped rects and spheres
                             }
                         } else {
                             int i = 0;

@@ -27,5 +27,7 @@ for scene_name in ("cornell_box.yml", "three_balls.yml", "noise_and_textures.yml
         sc.close()
     same = np.array_equal(frames[0], frames[1])
     bad += not same
-    print("%-24s %s  max |diff| %.3g" % (scene_name, "bit-identical" if same else "DIFFERENT", float(np.abs(frames[0] - frames[1]).max())))
+    differ = int((np.abs(frames[0] - frames[1]).max(axis=-1) > 0).sum())
+    print("%-24s %s  max |diff| %.3g  (%d of %d pixels differ)" % (scene_name, "bit-identical" if same else "DIFFERENT", float(np.abs(frames[0] - frames[1]).max()),
+                                                                  differ, p.width * p.height))
 sys.exit(1 if bad else 0)
