@@ -50,10 +50,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-from source_stamp import kernel_source_sha  # noqa: E402
+from source_stamp import kernel_source_sha, library_sha  # noqa: E402
 
 STRIP_ROWS = 8
-PMC_ROUND = "r03"              # profiles/<round>_<workload>_pmc_summary.json
+PMC_ROUND = "r04"              # profiles/<round>_<workload>_pmc_summary.json
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 SIMDS = 256 * 4                # 256 CUs x 4 SIMDs
 CLOCK_GHZ = 2.4                # MI355X_MICROARCH.md peak engine clock
@@ -160,6 +160,10 @@ def trace_kernel_counters(summary, workload_name, origin):
     stamp = summary.get("_stamp", {})
     if stamp.get("source_sha") != kernel_source_sha():
         return None, "%s was collected on other kernel sources (stamp mismatch): re-run tools/pmc.py" % origin
+    if stamp.get("library_sha") is not None and stamp.get("library_sha") != library_sha():
+        # a committed summary travels to another box, where the library is rebuilt: only a LIVE summary is held to the file
+        if origin.startswith("live"):
+            return None, "%s was collected on another build of the library" % origin
     if stamp.get("workload") != workload_name:
         return None, "%s is for %r" % (origin, stamp.get("workload"))
     kernels = [k for k in summary if "k_trace_pool_f64" in k]

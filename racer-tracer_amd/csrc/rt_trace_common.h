@@ -331,7 +331,7 @@ __device__ __forceinline__ bool sphere_t(d3 center, double radius2, d3 o, d3 d, 
 // of the box to within rounding: by comparing plane distances here, by comparing the in-plane point with the bounds
 // there (ties and such grazing rays are open, SURVEY B-15).  12 subtract/multiplies, 10 min/max and the side code
 // instead of six rects of 10 vector instructions and a select chain each.
-// `side` = box.rs's side index (box_side above): 2 * (2 - axis) + (the plane at box_min ? 1 : 0).
+// `side` = box.rs's side index (box_side above) of the pair's first plane: 2 * (2 - axis).
 // The RT_ARITH_REFERENCE kernels keep the six rect tests (the reference's own comparisons).
 __device__ __forceinline__ bool box_slab_t(const double *p, d3 o, d3 d, d3 inv_d, double t_min, double t_max, double &t_out,
                                            int &side) {
@@ -347,17 +347,13 @@ __device__ __forceinline__ bool box_slab_t(const double *p, d3 o, d3 d, d3 inv_d
     const double t_exit = fmin(fmin(x_far, y_far), z_far);
     const bool entry = t_enter >= t_min;
     const double t = entry ? t_enter : t_exit;
-    // which of the six planes t is: the axis whose near (far) distance it equals, and there the plane at box_min when
-    // that is the nearer (farther) one
-    int axis, at_min;
-    if (entry) {
-        axis = t == z_near ? 2 : (t == y_near ? 1 : 0);
-        at_min = axis == 2 ? z_mn <= z_mx : (axis == 1 ? y_mn <= y_mx : x_mn <= x_mx);
-    } else {
-        axis = t == z_far ? 2 : (t == y_far ? 1 : 0);
-        at_min = axis == 2 ? z_mn >= z_mx : (axis == 1 ? y_mn >= y_mx : x_mn >= x_mx);
-    }
-    side = 2 * (2 - axis) + at_min;
+    // Which pair of planes t belongs to: the axis whose nearer (farther) distance it equals.  Only the axis reaches the
+    // hit record (box_side: the rect's normal axis and in-plane bounds; which of the pair's two planes it was shows in
+    // nothing but t itself), so `side` is the even index of the pair.  Both candidates without a branch: as control
+    // flow the backend built three nested exec-mask regions per box around four moves.
+    const int side_in = t_enter == z_near ? 0 : (t_enter == y_near ? 2 : 4);
+    const int side_out = t_exit == z_far ? 0 : (t_exit == y_far ? 2 : 4);
+    side = entry ? side_in : side_out;
     t_out = t;
     return t_enter <= t_exit && t >= t_min && t <= t_max;
 }
@@ -427,6 +423,12 @@ __device__ __forceinline__ bool box_t(const Prim &P, d3 o, d3 d, d3 inv_d, doubl
 #ifdef RT_EXACT_DIV
     return prim_t<PRIMS_ANY>(P, o, d, inv_d, 0.0, 0.0, t_min, t_max, t_out, side);
 #else
+#ifndef RT_BOX_LOADS_LAZY
+    // everything the test reads of the record is requested before the first use: one scalar-load wait per box instead of
+    // three (offset + flags, sin / cos inside the rotated arm, the bounds): cornell_box_boxes +0.8 % at four waves per SIMD, +1.2 % at five
+    asm volatile("; box record requested" ::"s"(P.p[0]), "s"(P.p[1]), "s"(P.p[2]), "s"(P.p[3]), "s"(P.p[4]), "s"(P.p[5]), "s"(P.rot_sin),
+                 "s"(P.rot_cos), "s"(P.tr[0]), "s"(P.tr[1]), "s"(P.tr[2]), "s"(P.flags));
+#endif
     o = o - ld3(P.tr);
     if (P.flags & RT_PRIM_HAS_ROTATE_Y) {
         o = rot_fwd(o, P.rot_sin, P.rot_cos);

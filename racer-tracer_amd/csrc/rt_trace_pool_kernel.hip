@@ -75,7 +75,7 @@
 #define RT_OCC_SPEC 5
 #endif
 #ifndef RT_OCC_ANY
-#define RT_OCC_ANY 4 // untextured linear-loop variants with any primitive kind
+#define RT_OCC_ANY 5 // untextured linear-loop variants with any primitive kind (cornell_box_boxes: 4 -> 5 waves per SIMD 20.7 -> 19.3 ms)
 #endif
 #ifndef RT_OCC_PLAIN
 #define RT_OCC_PLAIN 6 // rects-only / spheres-only, no textures, no specular materials: 80 VGPRs, six blocks per CU when LDS allows (the bound is what keeps
@@ -1030,6 +1030,25 @@ __global__ __launch_bounds__(256) void k_resolve_chunks_f64(const double *__rest
 }
 
 } // namespace RT_KNS
+
+#if defined(RT_BB_COUNT) && !defined(RT_EXACT_DIV)
+// -DRT_BB_COUNT (tools/bb_build.sh, never the product): the basic-block counters that tools/bb_instrument.py's inserted
+// instructions add to, and the host call that reads them.  Nothing in the C++ below touches the array on the device.
+enum { RT_BB_MAX = 8192 };
+extern "C" {
+__device__ __attribute__((used)) unsigned long long rt_bb_counts[RT_BB_MAX];
+int rtdev_bb_counts(unsigned long long *out, int n, int reset) {
+    if (n > RT_BB_MAX) n = RT_BB_MAX;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(rt_bb_counts), (size_t)n * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long zeros[RT_BB_MAX];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(rt_bb_counts), zeros, sizeof zeros) != hipSuccess) return -1;
+    }
+    return n;
+}
+}
+#endif
 
 namespace {
 // One table entry per compiled variant: PRIMS x TEXTURED x SPECULAR with the

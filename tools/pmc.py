@@ -18,13 +18,14 @@ import csv
 import json
 import os
 import shutil
+import signal
 import subprocess
 import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-from source_stamp import kernel_source_sha  # noqa: E402
+from source_stamp import kernel_source_sha, library_sha  # noqa: E402
 
 # What bench.py's roofline block reads.  Four SQ counters per pass (the SQ has eight slots, derived counters take
 # several); the TCC byte counters get passes of their own as the guide prescribes.
@@ -49,11 +50,24 @@ def run_pass(counters, bench_args, keep_dir=None, timeout=240):
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--pmc"] + counters.split() + ["--output-format", "csv", "-d", work, "-o", "pmc", "--",
                                                      sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child"] + list(bench_args)
+    # The pass runs in its own session (process group): if it has to be cut off, the whole group goes — rocprofv3 AND the
+    # bench.py --pmc-child it started — so that no orphan keeps the GPU busy during the caller's timed steps.
     try:
-        run = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd="/tmp", timeout=timeout)
-    except (OSError, subprocess.TimeoutExpired) as e:
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd="/tmp", start_new_session=True)
+    except OSError as e:
         shutil.rmtree(work, ignore_errors=True)
         return None, None, "%s: %s" % (type(e).__name__, e)
+    try:
+        out, errtext = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired as e:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)  # pid == pgid: start_new_session
+        except OSError:
+            pass
+        proc.communicate()
+        shutil.rmtree(work, ignore_errors=True)
+        return None, None, "%s: %s (process group killed)" % (type(e).__name__, e)
+    run = subprocess.CompletedProcess(cmd, proc.returncode, out, errtext)
     bench = None
     for line in run.stdout.splitlines():
         if line.startswith("{"):
@@ -92,7 +106,7 @@ def collect(bench_args, groups=None, keep_dir=None, log=None, budget_s=None, pas
     import time
     t_begin = time.time()
     names = list(groups or STANDARD)
-    summary = {"_stamp": {"source_sha": kernel_source_sha(), "bench_args": " ".join(bench_args), "kernel_ms_under_pmc": [],
+    summary = {"_stamp": {"source_sha": kernel_source_sha(), "library_sha": library_sha(), "bench_args": " ".join(bench_args), "kernel_ms_under_pmc": [],
                           "groups": {}, "errors": []}}
     stamp = summary["_stamp"]
     for name in names:

@@ -57,5 +57,21 @@ def kernel_source_sha():
     return h.hexdigest()
 
 
+def library_path():
+    """The library bench.py will load: RACER_TRACER_AMD_LIB (a developer / A-B build) or the shipped one."""
+    return os.environ.get("RACER_TRACER_AMD_LIB") or os.path.join(ROOT, "racer-tracer_amd", "lib", "libracer_tracer_amd.so")
+
+
+def library_sha():
+    """SHA-256 of the library FILE the counters are collected on (None when it is not built): the source stamp does not see
+    build flags (RT_OCC_*, AB_FLAGS) or a RACER_TRACER_AMD_LIB override, this does."""
+    try:
+        with open(library_path(), "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()
+    except OSError:
+        return None
+
+
 if __name__ == "__main__":
     print(kernel_source_sha())
+    print(library_sha(), library_path())
