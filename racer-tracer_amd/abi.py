@@ -124,6 +124,7 @@ PROTOTYPES = {
     "rt_scene_create": (C.c_int, [C.POINTER(RtSceneDesc), C.c_int, C.POINTER(C.c_void_p)]),
     "rt_scene_create_ex": (C.c_int, [C.POINTER(RtSceneDesc), C.c_int, C.POINTER(RtSceneOptions), C.POINTER(C.c_void_p)]),
     "rt_scene_destroy": (None, [C.c_void_p]),
+    "rt_release_cached_buffers": (None, []),
     "rt_render_frame": (C.c_int, [C.c_void_p, C.POINTER(RtCamera), C.POINTER(RtRenderParams),
                                   C.POINTER(C.c_double)]),
     "rt_render_frame_device": (C.c_int, [C.c_void_p, C.POINTER(RtCamera),

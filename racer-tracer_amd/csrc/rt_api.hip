@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <cmath>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -454,6 +455,125 @@ int rtapi::poison_queue(RtScene *s) {
     return RT_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------- render-buffer cache
+// Everything a render call allocates on first use, kept per device across rt_scene_destroy / rt_scene_create.
+// Measured on 1 x MI355X at 1080p (tools/time_scene_create.py, profiles/r04_scene_create.txt): rt_scene_create itself
+// is 0.3 - 1.4 ms, but the first render of a new scene paid 3 ms of hipMalloc / hipHostMalloc (50 MB pinned frame,
+// slices, counters) and the destroy before it 1 - 4 ms of hipFree / hipHostFree — on every object event of the
+// reference's interactive loop.  At most two sets per device are kept (two scenes alive at a time is the pattern of
+// `rebuild, then drop the old one`); rt_release_cached_buffers gives the memory back.
+namespace {
+struct RenderBuffers {
+    int device = -1;
+    DevBuf<double> partial, accum, frame;
+    DevBuf<unsigned int> queue, tile_done, region_done;
+    DevBuf<uint8_t> rgba;
+    DevBuf<unsigned long long> segments;
+    double *host_frame = nullptr;
+    size_t host_frame_count = 0;
+    unsigned int *host_flags = nullptr;
+    uint32_t deliver_serial = 0; // the flags still hold the serials this scene published: the counter moves on
+    bool deliver_dirty = false;
+    hipStream_t stream = nullptr, stream_ctl = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_traced = nullptr, ev_resolved = nullptr;
+    void free_all() {
+        if (device < 0) return;
+        (void)hipSetDevice(device);
+        partial.release();
+        accum.release();
+        frame.release();
+        queue.release();
+        tile_done.release();
+        region_done.release();
+        rgba.release();
+        segments.release();
+        if (host_frame) (void)hipHostFree(host_frame);
+        if (host_flags) (void)hipHostFree(host_flags);
+        if (ev_begin) (void)hipEventDestroy(ev_begin);
+        if (ev_traced) (void)hipEventDestroy(ev_traced);
+        if (ev_resolved) (void)hipEventDestroy(ev_resolved);
+        if (stream) (void)hipStreamDestroy(stream);
+        if (stream_ctl) (void)hipStreamDestroy(stream_ctl);
+        device = -1;
+    }
+};
+std::mutex g_cache_mutex;
+std::vector<RenderBuffers> g_cache;
+const size_t kCachedSetsPerDevice = 2;
+
+template <class T> void move_buf(DevBuf<T> &to, DevBuf<T> &from) {
+    to.ptr = from.ptr;
+    to.count = from.count;
+    from.ptr = nullptr;
+    from.count = 0;
+}
+void move_render_buffers(RenderBuffers &b, RtScene *s, bool to_scene) {
+#define RT_MOVE(member) do { if (to_scene) move_buf(s->member, b.member); else move_buf(b.member, s->member); } while (0)
+    RT_MOVE(partial);
+    RT_MOVE(accum);
+    RT_MOVE(frame);
+    RT_MOVE(queue);
+    RT_MOVE(tile_done);
+    RT_MOVE(region_done);
+    RT_MOVE(rgba);
+    RT_MOVE(segments);
+#undef RT_MOVE
+#define RT_SWAP(member) do { if (to_scene) s->member = b.member; else b.member = s->member; } while (0)
+    RT_SWAP(host_frame);
+    RT_SWAP(host_frame_count);
+    RT_SWAP(host_flags);
+    RT_SWAP(deliver_serial);
+    RT_SWAP(deliver_dirty);
+    RT_SWAP(stream);
+    RT_SWAP(stream_ctl);
+    RT_SWAP(ev_begin);
+    RT_SWAP(ev_traced);
+    RT_SWAP(ev_resolved);
+#undef RT_SWAP
+    if (!to_scene) {
+        s->host_frame = nullptr;
+        s->host_frame_count = 0;
+        s->host_flags = nullptr;
+        s->stream = s->stream_ctl = nullptr;
+        s->ev_begin = s->ev_traced = s->ev_resolved = nullptr;
+    }
+}
+// rt_scene_destroy: the scene's render buffers go to the cache (or are freed when the device's slots are taken or the
+// scene never got as far as creating its streams)
+void render_cache_put(RtScene *s) {
+    RenderBuffers b;
+    b.device = s->device;
+    move_render_buffers(b, s, false);
+    const bool complete = b.stream && b.stream_ctl && b.ev_begin && b.ev_traced && b.ev_resolved && b.host_flags && b.segments.ptr;
+    if (complete) {
+        std::lock_guard<std::mutex> lock(g_cache_mutex);
+        size_t held = 0;
+        for (const RenderBuffers &c : g_cache) held += c.device == b.device;
+        if (held < kCachedSetsPerDevice) {
+            g_cache.push_back(b);
+            return;
+        }
+    }
+    b.free_all();
+}
+// rt_scene_create: take over a cached set of this device (the one with the largest slices), if there is one
+bool render_cache_take(RtScene *s) {
+    RenderBuffers b;
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mutex);
+        int best = -1;
+        for (size_t i = 0; i < g_cache.size(); ++i)
+            if (g_cache[i].device == s->device && (best < 0 || g_cache[i].partial.count > g_cache[(size_t)best].partial.count)) best = (int)i;
+        if (best < 0) return false;
+        b = g_cache[(size_t)best];
+        g_cache.erase(g_cache.begin() + best);
+    }
+    move_render_buffers(b, s, true);
+    return true;
+}
+} // namespace
+
 extern "C" {
 
 int rt_abi_version(void) { return RT_ABI_VERSION; }
@@ -504,6 +624,7 @@ void rt_scene_destroy(RtScene *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->stream_ctl) (void)hipStreamSynchronize(s->stream_ctl);
     for (uint8_t *p : s->image_pixels)
         if (p) (void)hipFree(p);
     s->prims.release();
@@ -513,22 +634,20 @@ void rt_scene_destroy(RtScene *s) {
     s->bvh_nodes.release();
     s->bvh_prim_index.release();
     s->leaf_geo.release();
-    s->accum.release();
-    s->partial.release();
-    s->queue.release();
-    s->frame.release();
-    s->rgba.release();
-    s->segments.release();
-    if (s->ev_begin) (void)hipEventDestroy(s->ev_begin);
-    if (s->ev_traced) (void)hipEventDestroy(s->ev_traced);
-    if (s->ev_resolved) (void)hipEventDestroy(s->ev_resolved);
-    s->tile_done.release();
-    s->region_done.release();
-    if (s->host_frame) (void)hipHostFree(s->host_frame);
-    if (s->host_flags) (void)hipHostFree(s->host_flags);
-    if (s->stream) (void)hipStreamDestroy(s->stream);
-    if (s->stream_ctl) (void)hipStreamDestroy(s->stream_ctl);
+    // what a render allocates — slices, frames, pinned memory, counters, streams, events — outlives the scene: the
+    // reference rebuilds its scene on every object event (main.rs:174-189), and the next rt_scene_create on this
+    // device takes these over instead of paying hipMalloc / hipHostMalloc again (render_cache below)
+    render_cache_put(s);
     delete s;
+}
+
+void rt_release_cached_buffers(void) {
+    std::vector<RenderBuffers> all;
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mutex);
+        all.swap(g_cache);
+    }
+    for (RenderBuffers &b : all) b.free_all();
 }
 
 int rt_scene_create(const RtSceneDesc *d, int device, RtScene **out) { return rt_scene_create_ex(d, device, nullptr, out); }
@@ -780,16 +899,18 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
     if (const char *k = getenv("RT_POOL_BLOCKS_PER_CU"))
         if (atoi(k) > 0) s->pool_blocks_per_cu = s->pool_blocks_per_cu_lens = atoi(k);
 #endif
-    RT_HIP(s->segments.alloc(rtdev::RT_STAT_SLOTS)); // rt_device_types.h: RT_STAT_*
-    RT_HIP(hipMemset(s->segments.ptr, 0, rtdev::RT_STAT_SLOTS * sizeof(unsigned long long)));
-    RT_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-    RT_HIP(hipEventCreate(&s->ev_begin));
-    RT_HIP(hipEventCreate(&s->ev_traced));
-    RT_HIP(hipEventCreate(&s->ev_resolved));
-    RT_HIP(hipHostMalloc((void **)&s->host_flags, rtdev::RT_MAX_REGIONS * sizeof(unsigned int),
-                         hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
-    memset(s->host_flags, 0, rtdev::RT_MAX_REGIONS * sizeof(unsigned int));
-    RT_HIP(hipStreamCreateWithFlags(&s->stream_ctl, hipStreamNonBlocking));
+    if (!render_cache_take(s)) { // nothing of this device's to take over: the first scene, or more than the cache holds
+        RT_HIP(s->segments.alloc(rtdev::RT_STAT_SLOTS)); // rt_device_types.h: RT_STAT_*
+        RT_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        RT_HIP(hipEventCreate(&s->ev_begin));
+        RT_HIP(hipEventCreate(&s->ev_traced));
+        RT_HIP(hipEventCreate(&s->ev_resolved));
+        RT_HIP(hipHostMalloc((void **)&s->host_flags, rtdev::RT_MAX_REGIONS * sizeof(unsigned int),
+                             hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
+        memset(s->host_flags, 0, rtdev::RT_MAX_REGIONS * sizeof(unsigned int));
+        RT_HIP(hipStreamCreateWithFlags(&s->stream_ctl, hipStreamNonBlocking));
+    }
+    RT_HIP(hipMemsetAsync(s->segments.ptr, 0, rtdev::RT_STAT_SLOTS * sizeof(unsigned long long), s->stream));
     guard.s = nullptr;
     *out = s;
     return RT_OK;

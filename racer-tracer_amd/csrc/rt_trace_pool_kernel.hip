@@ -913,7 +913,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                 }
             }
             RT_REGION(10); // Noise rounds
-            d3 sph = mk(0.0, 0.0, 0.0);
+            d3 sph; // only read by the lanes the sampler returns true for, which it has assigned
             if (coop_random_in_unit_sphere(waiting, rng.pixel, rng.sample, seg, cand_base, A.seed_lo, A.seed_hi, lane,
                                            L.scratch.req, (TEXTURED || SPECULAR) ? 4 : 2, sph)) {
                 waiting = false;

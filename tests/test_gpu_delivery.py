@@ -240,6 +240,45 @@ def test_shares_that_own_no_rows(rt, gpu):
             s.close()
 
 
+def test_render_buffers_survive_scene_rebuilds(rt, gpu):
+    """The reference rebuilds its scene on every object event (main.rs:174-189); rt_scene_destroy hands what a render
+    allocated (slices, pinned frame, flags, counters, streams) to the next rt_scene_create on the device.  A rebuilt
+    scene — another description, another frame size, delivering and two-pass calls mixed — must render exactly what a
+    scene with fresh buffers renders: the host-visible flags still hold the serials of the previous owner, the tile
+    counters must be at zero, the slices may be larger or smaller than the new frame needs."""
+    cases = [(S.cornell_box, 200, 120, 40), (S.three_balls, 96, 54, 8), (S.cornell_box_boxes, 333, 64, 12), (S.cornell_box, 200, 120, 40)]
+    rt.lib().rt_release_cached_buffers()                     # whatever earlier tests left behind
+    fresh = []
+    for make, w, h, spp in cases:                             # every scene on buffers of its own
+        bundle, cam, _ = make()
+        scene = rt.Scene(bundle)
+        fresh.append(two_pass_frame(scene, S.camera_for(cam, w, h), S.abi.render_params(w, h, spp)))
+        scene.close()
+        rt.lib().rt_release_cached_buffers()
+    for round_ in range(2):
+        for (make, w, h, spp), want in zip(cases, fresh):     # ... and now handing them down from scene to scene
+            bundle, cam, _ = make()
+            camera, params = S.camera_for(cam, w, h), S.abi.render_params(w, h, spp, tiles_w=5, tiles_h=3)
+            scene = rt.Scene(bundle)
+            try:
+                assert np.array_equal(scene.render_frame(camera, params), want)
+                stitched = np.full_like(want, -1.0)
+                for r, c, tw, th, arr in scene.render_tiles(camera, params):
+                    stitched[r:r + th, c:c + tw] = arr
+                assert np.array_equal(stitched, want)
+                assert np.array_equal(two_pass_frame(scene, camera, params), want)
+            finally:
+                scene.close()
+    a, b = rt.Scene(cases[0][0]()[0]), rt.Scene(cases[1][0]()[0])   # two alive at once: two sets, no sharing
+    try:
+        for sc, (make, w, h, spp), want in ((a, cases[0], fresh[0]), (b, cases[1], fresh[1])):
+            assert np.array_equal(sc.render_frame(S.camera_for(make()[1], w, h), S.abi.render_params(w, h, spp)), want)
+    finally:
+        a.close()
+        b.close()
+    rt.lib().rt_release_cached_buffers()
+
+
 def test_paths_that_do_not_deliver_still_stream_tiles(rt, gpu):
     """The v1 kernel and the preview scale render with the two-pass path and cut the tiles from the finished frame
     (rt_deliver.hip: tiles_from_frame): same tiles, the cancel callback honoured; several devices refuse them."""
