@@ -254,7 +254,7 @@ void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtd
         a.bvh_root_mx[k] = s->bvh_root_mx[k];
         a.bvh_center[k] = s->bvh_center[k];
     }
-    a.bvh_lds_nodes = s->bvh_nodes_in_lds ? s->n_bvh_nodes : 0;
+    a.bvh_lds_nodes = s->bvh_nodes_in_lds ? s->n_bvh_nodes + 1 : 0; // the sentinel behind the tree's nodes is staged too
     a.leaf_geo = s->leaf_geo.ptr;
     a.leaf_time_a = s->leaf_time_a;
     a.leaf_inv_dt = s->leaf_inv_dt;
@@ -830,7 +830,7 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
         }
         if ((rc = upload(s->bvh_nodes, bvh.nodes)) != RT_OK) return rc;
         if ((rc = upload(s->bvh_prim_index, bvh.prim_index)) != RT_OK) return rc;
-        s->n_bvh_nodes = (int)bvh.nodes.size();
+        s->n_bvh_nodes = (int)bvh.nodes.size() - 1; // the array ends with the sentinel (rt_device_types.h: BvhNode)
         for (int k = 0; k < 3; ++k) {
             s->bvh_root_mn[k] = bvh.root_mn[k];
             s->bvh_root_mx[k] = bvh.root_mx[k];
@@ -884,12 +884,12 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
     }
     s->use_v1 = opt.kernel == RT_KERNEL_V1;
     RT_HIP(hipDeviceGetAttribute(&s->num_cus, hipDeviceAttributeMultiprocessorCount, device));
-    s->bvh_nodes_in_lds = s->use_bvh && (size_t)s->n_bvh_nodes * sizeof(rtdev::BvhNode) <= 32 * 1024;
+    s->bvh_nodes_in_lds = s->use_bvh && (size_t)(s->n_bvh_nodes + 1) * sizeof(rtdev::BvhNode) <= 32 * 1024;
 #ifdef RT_DEVELOPER_KNOBS
     if (const char *k = getenv("RT_BVH_LDS")) s->bvh_nodes_in_lds = s->bvh_nodes_in_lds && atoi(k) != 0;
 #endif
     // dynamic LDS of the variant: the BVH node array, or the primitive table of the linear-loop variants
-    const size_t dyn_lds = (s->use_bvh ? (s->bvh_nodes_in_lds ? (size_t)s->n_bvh_nodes * sizeof(rtdev::BvhNode) : 0)
+    const size_t dyn_lds = (s->use_bvh ? (s->bvh_nodes_in_lds ? (size_t)(s->n_bvh_nodes + 1) * sizeof(rtdev::BvhNode) : 0)
                                        : (size_t)s->n_prims * sizeof(rtdev::Prim) + (s->textured ? (size_t)s->n_textures * sizeof(rtdev::Texture) : 0)) +
                            (s->textured && s->n_perlins > 0 && s->perlin_identity ? sizeof(double) * 256 * 3 : 0);
     s->pool_blocks_per_cu = (s->exact ? rtdev_pool_blocks_per_cu_exact : rtdev_pool_blocks_per_cu)(s->prims_class, s->textured, s->specular, s->use_bvh, dyn_lds);

@@ -195,29 +195,37 @@ BvhBuild build_bvh(const RtPrimitive *prims, int n_prims, int max_leaf) {
     out.prim_index = tree.prim_index;
     // Device form: f32 boxes around the root's centre.  A ray is clipped to the root box in f64 before the walk, so
     // its origin is at most `extent` from the centre and the f32 slab test is off by a few 2^-24 * extent in the
-    // plane positions: the boxes are padded by 2^-20 * extent and rounded outward.
+    // plane positions: the boxes are padded by 2^-19 * extent and rounded outward (rt_bvh_slab.h has the error budget).
     const Node64 &root = tree.nodes[0];
     double extent = 0.0;
     for (int k = 0; k < 3; ++k) {
         out.center[k] = 0.5 * (root.mn[k] + root.mx[k]);
         extent = std::max(extent, 0.5 * (root.mx[k] - root.mn[k]));
     }
-    const double pad = std::ldexp(extent, -20);
+    const double pad = std::ldexp(extent, -19);
     for (int k = 0; k < 3; ++k) {
         out.root_mn[k] = root.mn[k] - pad;
         out.root_mx[k] = root.mx[k] + pad;
     }
-    out.nodes.resize(tree.nodes.size());
+    out.nodes.resize(tree.nodes.size() + 1);
     for (size_t i = 0; i < tree.nodes.size(); ++i) {
         const Node64 &n = tree.nodes[i];
         BvhNode &q = out.nodes[i];
         for (int k = 0; k < 3; ++k) {
-            q.mn[k] = round_down(n.mn[k] - out.center[k] - pad);
-            q.mx[k] = round_up(n.mx[k] - out.center[k] + pad);
+            q.lohi[2 * k] = round_down(n.mn[k] - out.center[k] - pad);
+            q.lohi[2 * k + 1] = round_up(n.mx[k] - out.center[k] + pad);
         }
         q.skip = n.skip;
         q.first_count = n.count > 0 ? (n.first << 3) | n.count : 0;
     }
+    // the sentinel (rt_device_types.h: BvhNode): all of space, a leaf without primitives, one step past the end
+    BvhNode &end = out.nodes.back();
+    for (int k = 0; k < 3; ++k) {
+        end.lohi[2 * k] = -INFINITY;
+        end.lohi[2 * k + 1] = INFINITY;
+    }
+    end.skip = (int32_t)out.nodes.size();
+    end.first_count = BvhNode::kSentinel;
     return out;
 }
 

@@ -25,7 +25,7 @@
 namespace rtdev {
 
 struct BvhBuild {
-    std::vector<BvhNode> nodes;      // compact device form (rt_device_types.h)
+    std::vector<BvhNode> nodes;      // compact device form (rt_device_types.h); the LAST entry is the sentinel, not a node of the tree
     std::vector<int32_t> prim_index; // leaves refer to ranges of this list
     double root_mn[3], root_mx[3];   // root box, f64, padded like the node boxes
     double center[3];                // the node boxes are relative to this point

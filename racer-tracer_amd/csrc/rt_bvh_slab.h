@@ -4,7 +4,7 @@
 // v_max_f32 perform, so the model tests the device's arithmetic, not a restatement of it.
 //
 // The node boxes only CULL (primitives are tested in f64), so they are f32 boxes around the root's centre, padded by
-// 2^-20 of the scene's extent and rounded outward (rt_bvh.cpp); the ray is clipped to the root box in f64 first.
+// 2^-19 of the scene's extent and rounded outward (rt_bvh.cpp); the ray is clipped to the root box in f64 first.
 #pragma once
 #include <math.h>
 
@@ -16,9 +16,9 @@
 
 namespace rtdev {
 
-struct SlabRay {       // a ray prepared for the f32 slab tests
+struct SlabRay {       // a ray prepared for the f32 slab tests: six consecutive floats = the register pairs (ivx, ivy), (ivz, nox), (noy, noz)
     float ivx, ivy, ivz; // 1 / direction, clamped to a finite magnitude
-    float oix, oiy, oiz; // (origin - centre) * iv
+    float nox, noy, noz; // -(origin - centre) * iv
 };
 
 // 1/d as the slab test wants it.  A direction component of exactly 0 (an axis-parallel ray) has 1/d = +-inf, and
@@ -34,39 +34,31 @@ RT_SLAB_FN SlabRay slab_ray(float ofx, float ofy, float ofz, double inv_dx, doub
     r.ivx = slab_finite((float)inv_dx);
     r.ivy = slab_finite((float)inv_dy);
     r.ivz = slab_finite((float)inv_dz);
-    r.oix = ofx * r.ivx;
-    r.oiy = ofy * r.ivy;
-    r.oiz = ofz * r.ivz;
+    r.nox = -(ofx * r.ivx);
+    r.noy = -(ofy * r.ivy);
+    r.noz = -(ofz * r.ivz);
     return r;
 }
 
-// Does the ray's window [tmin_f, best_f] (seen from the clipped origin, already rounded outward) overlap the box?
-// `slack` is the relative slack of the interval test (2^-20: the f32 plane distances are good to 2^-23 relative).
-// On the device the minima and maxima are written as the instructions themselves: through fminf / fmaxf the compiler
-// re-canonicalises the loop-carried window ends (v_max_f32 x, x) on EVERY node, two of the step's 26 vector
-// instructions, because it cannot prove them free of signalling NaNs.  v_min / v_max return the non-NaN operand like
-// fminf / fmaxf do, so the host form below is the same function.
-RT_SLAB_FN bool slab_hit(const float mn[3], const float mx[3], const SlabRay &r, float tmin_f, float best_f, float slack) {
-    const float ax = fmaf(mn[0], r.ivx, -r.oix), bx = fmaf(mx[0], r.ivx, -r.oix);
-    const float ay = fmaf(mn[1], r.ivy, -r.oiy), by = fmaf(mx[1], r.ivy, -r.oiy);
-    const float az = fmaf(mn[2], r.ivz, -r.oiz), bz = fmaf(mx[2], r.ivz, -r.oiz);
-#if defined(__HIP_DEVICE_COMPILE__)
-    float nx, ny, nz, fx, fy, fz, t_near, t_far;
-    asm("v_min_f32 %0, %1, %2" : "=v"(nx) : "v"(ax), "v"(bx));
-    asm("v_max_f32 %0, %1, %2" : "=v"(fx) : "v"(ax), "v"(bx));
-    asm("v_min_f32 %0, %1, %2" : "=v"(ny) : "v"(ay), "v"(by));
-    asm("v_max_f32 %0, %1, %2" : "=v"(fy) : "v"(ay), "v"(by));
-    asm("v_min_f32 %0, %1, %2" : "=v"(nz) : "v"(az), "v"(bz));
-    asm("v_max_f32 %0, %1, %2" : "=v"(fz) : "v"(az), "v"(bz));
-    asm("v_max_f32 %0, %1, %2" : "=v"(nz) : "v"(nz), "v"(tmin_f));
-    asm("v_min_f32 %0, %1, %2" : "=v"(fz) : "v"(fz), "v"(best_f));
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t_near) : "v"(nx), "v"(ny), "v"(nz));
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t_far) : "v"(fx), "v"(fy), "v"(fz));
-#else
+// Does the ray's window [tmin_f, best_f] (seen from the clipped origin, already rounded outward) overlap the box
+// lohi = {mn.x, mx.x, mn.y, mx.y, mn.z, mx.z} (BvhNode's layout)?
+// No slack in the comparison: every plane distance is off by less than the box's own padding moves it.  With E the
+// scene's extent, |coordinate| <= E and |origin - centre| <= E after the clip to the root box; the fma rounds once
+// (2^-24 of a result below 2 E |iv|), (origin - centre) and iv were each rounded to f32 once (2^-24 relative): under
+// 6 x 2^-24 E |iv| in all, and the planes are padded by 2^-19 E (rt_bvh.cpp), i.e. 2^-19 E |iv| in t — three times
+// that.  So a ray that meets the unpadded box in exact arithmetic has t_near <= t_far here.  (Rounds 2 and 3 carried a
+// relative slack of 2^-20 on t_far instead, one v_fma_f32 per node on top of a 2^-20 E padding.)
+// On the device (closest_hit_bvh) the six plane distances are three v_pk_fma_f32 — each half a true fma, like fmaf —
+// and the minima and maxima are written as the instructions themselves: through fminf / fmaxf the compiler
+// re-canonicalises the loop-carried window ends (v_max_f32 x, x) on EVERY node because it cannot prove them free of
+// signalling NaNs.  v_min / v_max return the non-NaN operand like fminf / fmaxf do, so this host form is the same function.
+RT_SLAB_FN bool slab_hit(const float lohi[6], const SlabRay &r, float tmin_f, float best_f) {
+    const float ax = fmaf(lohi[0], r.ivx, r.nox), bx = fmaf(lohi[1], r.ivx, r.nox);
+    const float ay = fmaf(lohi[2], r.ivy, r.noy), by = fmaf(lohi[3], r.ivy, r.noy);
+    const float az = fmaf(lohi[4], r.ivz, r.noz), bz = fmaf(lohi[5], r.ivz, r.noz);
     const float t_near = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin_f));
     const float t_far = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best_f));
-#endif
-    return t_near <= fmaf(fabsf(t_far), slack, t_far);
+    return t_near <= t_far;
 }
 
 } // namespace rtdev

@@ -72,12 +72,19 @@ struct Perlin { // gradient table only: perm tables are folded into `index`
 
 // 32 B; depth-first order with a skip link (rt_bvh.h).  The box is for CULLING only, so it is kept in single
 // precision: coordinates relative to the root box's centre (TraceArgs.bvh_center), rounded outward and padded by
-// 2^-20 of the scene's extent — more than the f32 slab test of a ray whose origin lies inside the root box can be
-// off by (closest_hit_bvh clips the ray to the root box in f64 first).  Primitives are tested in f64 as everywhere.
+// 2^-19 of the scene's extent — more than the f32 slab test of a ray whose origin lies inside the root box can be
+// off by (rt_bvh_slab.h; closest_hit_bvh clips the ray to the root box in f64 first).  Primitives are tested in f64 as
+// everywhere.  The two planes of an axis sit side by side, so that one v_pk_fma_f32 forms both distances.
+// The array ends with a SENTINEL at index n: an all-space box that is a leaf without primitives — the node every
+// finished walk arrives at through its last skip link and "hits", so the descent loop has ONE way out (a leaf was
+// entered) and no `i < n` test per step.
 struct alignas(16) BvhNode {
-    float mn[3], mx[3];
-    int32_t skip;         // next node when this subtree is finished or missed (n_nodes = done)
-    int32_t first_count;  // leaf: (first primitive of the leaf << 3) | number of primitives (1..4); inner: 0
+    float lohi[6];        // mn.x, mx.x, mn.y, mx.y, mn.z, mx.z
+    int32_t skip;         // next node when this subtree is finished or missed (n = the sentinel)
+    int32_t first_count;  // leaf: (first primitive of the leaf << 3) | number of primitives (1..7); inner: 0; sentinel: kSentinel
+    float mn(int k) const { return lohi[2 * k]; }
+    float mx(int k) const { return lohi[2 * k + 1]; }
+    static constexpr int32_t kSentinel = 1 << 30; // a leaf (non-zero) of zero primitives
 };
 static_assert(sizeof(BvhNode) == 32, "BvhNode must be 32 bytes");
 
@@ -202,8 +209,8 @@ struct TraceArgs {
     double bvh_root_mn[3], bvh_root_mx[3]; // the root box in f64 (padded like the node boxes)
     double bvh_center[3];                  // origin of the node boxes' coordinates
     const int32_t *bvh_prim_index;
-    int32_t n_bvh_nodes;
-    int32_t bvh_lds_nodes; // == n_bvh_nodes when the node array is staged in dynamic LDS, else 0
+    int32_t n_bvh_nodes;   // without the sentinel that follows them in the array
+    int32_t bvh_lds_nodes; // == n_bvh_nodes + 1 (the sentinel is staged too) when the node array is staged in dynamic LDS, else 0
     const LeafGeo *leaf_geo;             // per primitive of the (leaf-ordered) table
     double leaf_time_a, leaf_inv_dt;     // MovingSphere.time_a and 1 / (time_b - time_a) of the tag-0 records
     // Linear-loop variants: the device table is grouped — untransformed XY rects first, then XZ, then YZ

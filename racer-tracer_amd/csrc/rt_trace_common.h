@@ -474,35 +474,57 @@ __device__ __forceinline__ void closest_hit_bvh(const TraceArgs &A, const BvhNod
     }
     const SlabRay sr = slab_ray((float)(fma(t0, d.x, o.x) - K->bvh_center[0]), (float)(fma(t0, d.y, o.y) - K->bvh_center[1]),
                                 (float)(fma(t0, d.z, o.z) - K->bvh_center[2]), inv_d.x, inv_d.y, inv_d.z); // rt_bvh_slab.h
-    const float slack = 0x1p-20f;
+    const float slack = 0x1p-20f; // of the WINDOW ends only (f64 -> f32, rounded outward); the box test itself carries none
     // the window [t_min, best_t] seen from the clipped origin, rounded outward
     const float tmin_f = (float)(t_min - t0) - fabsf((float)(t_min - t0)) * slack - 0x1p-126f;
-    auto far_of = [&](double bt) { // upper end of the window
+    auto far_of = [&](double bt) { // upper end of the window; never below its lower end, so that the sentinel is always "hit"
         const float f = (float)(bt - t0);
-        return f + fabsf(f) * slack;
+        return fmaxf(f + fabsf(f) * slack, tmin_f);
     };
     float best_f = far_of(best_t);
+    if (!(tmin_f <= best_f)) return; // NaN somewhere in the ray: nothing can be hit (and the walk below relies on the order)
+    // the ray's six constants as the three register pairs v_pk_fma_f32 reads (SlabRay's order)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 p01 = {sr.ivx, sr.ivy}, p23 = {sr.ivz, sr.nox}, p45 = {sr.noy, sr.noz};
     int i = 0;
     const int n = A.n_bvh_nodes;
     while (i < n) {
-        int count = 0, first = 0;
-        while (i < n) { // descend / skip until a leaf is entered
+        int fc = 0;
+        // DESCENT: skip / step down until a leaf is entered.  The array ends with a sentinel — an all-space leaf without
+        // primitives at index n, where every finished walk arrives through its last skip link — so the loop has ONE
+        // exit and no `i < n` test per step.  It ends for every lane: the index grows with every step (i + 1, or a skip
+        // link, which points forward), and at index n the test below cannot fail — the sentinel's planes are at -inf /
+        // +inf (or NaN, which v_min / v_max drop), leaving t_near = tmin_f and t_far = best_f, which are ordered and not
+        // NaN (checked above; far_of keeps best_f there).  The step is what the walk is made of (58 % of the
+        // BVH variant's vector instructions, profiles/r04_random_opcode_hist.txt), so it is written out: both planes of
+        // an axis in one v_pk_fma_f32 (the node keeps them side by side), min / max as the instructions, no slack
+        // fma (rt_bvh_slab.h has the error budget), the leaf test on the raw first_count word.
+        for (;;) {
             if (walk_stats) ++walk_stats[0]; // profile build: nodes visited
-            // The whole 32-byte node in two 128-bit reads BEFORE the test, and the step without a branch: with the
-            // links read inside the hit / miss arms every step was two dependent LDS round trips and a dozen scalar
-            // instructions of exec-mask bookkeeping (profiles/r03_random_pmc_summary.json: a wave of the walk waits
-            // on s_waitcnt for 44 % of its time).
             const uint4 *raw = reinterpret_cast<const uint4 *>(&nodes[i]);
-            const uint4 q0 = raw[0], q1 = raw[1];
-            const float mn[3] = {__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)};
-            const float mx[3] = {__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)};
-            const int skip = (int)q1.z, fc = (int)q1.w;
-            const bool hit = slab_hit(mn, mx, sr, tmin_f, best_f, slack);
-            i = hit ? i + 1 : skip; // inner: first child; leaf: its skip link is i + 1 as well
-            count = hit ? (fc & 7) : 0;
-            first = fc >> 3;
-            if (count > 0) break;
+            const uint4 q0 = raw[0], q1 = raw[1]; // the whole 32-byte node in two 128-bit reads BEFORE the test
+            const f2 qx = {__uint_as_float(q0.x), __uint_as_float(q0.y)}, qy = {__uint_as_float(q0.z), __uint_as_float(q0.w)},
+                     qz = {__uint_as_float(q1.x), __uint_as_float(q1.y)};
+            f2 tx, ty, tz;
+            float nx, ny, nz, fx, fy, fz, t_near, t_far;
+            // (lo, hi) * (iv, iv) + (no, no): op_sel picks the half of each 64-bit source for the low result, op_sel_hi for the high one
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(tx) : "v"(qx), "v"(p01), "v"(p23)); // x: ivx = p01.lo, nox = p23.hi
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(ty) : "v"(qy), "v"(p01), "v"(p45)); // y: ivy = p01.hi, noy = p45.lo
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(tz) : "v"(qz), "v"(p23), "v"(p45)); // z: ivz = p23.lo, noz = p45.hi
+            // (one statement: between separate asm statements the compiler puts an s_nop for hazards it cannot rule out)
+            asm("v_min_f32 %0, %8, %9\n\tv_max_f32 %1, %8, %9\n\t"
+                "v_min_f32 %2, %10, %11\n\tv_max_f32 %3, %10, %11\n\t"
+                "v_min_f32 %4, %12, %13\n\tv_max_f32 %5, %12, %13\n\t"
+                "v_max_f32 %4, %4, %14\n\tv_min_f32 %5, %5, %15\n\t"
+                "v_max3_f32 %6, %0, %2, %4\n\tv_min3_f32 %7, %1, %3, %5"
+                : "=&v"(nx), "=&v"(fx), "=&v"(ny), "=&v"(fy), "=&v"(nz), "=&v"(fz), "=&v"(t_near), "=&v"(t_far)
+                : "v"(tx.x), "v"(tx.y), "v"(ty.x), "v"(ty.y), "v"(tz.x), "v"(tz.y), "v"(tmin_f), "v"(best_f));
+            const bool hit = !(t_near > t_far); // (a NaN, which the window's ends exclude, would step on: the walk still ends)
+            fc = (int)q1.w;
+            i = hit ? i + 1 : (int)q1.z; // inner: first child; leaf: its skip link is i + 1 as well
+            if (hit && fc != 0) break; // a leaf (or the sentinel) was entered
         }
+        const int count = fc & 7, first = fc >> 3; // the sentinel: no primitives, and i = n + 1 ends the walk
         mark(11); // profile build: the descent
         bool improved = false;
         for (int k = 0; k < count; ++k) { // the leaf's primitives (stored contiguously in leaf order)
@@ -511,13 +533,16 @@ __device__ __forceinline__ void closest_hit_bvh(const TraceArgs &A, const BvhNod
             double t;
             int aux = 0;
             bool hit;
+            // The compact record is read and the sphere test run WITHOUT asking the tag first: behind `if (G.tag == 0)`
+            // a leaf primitive cost two dependent round trips to global memory (the tag, then the record), and the leaf
+            // tests were 30 % of the `random` frame's wave time for 14 % of its vector instructions
+            // (profiles/r04_region_cycles.txt).  A record of another kind (tag 1) holds zeros here: its sphere test is
+            // discarded and the general routine runs for it — in scenes of spheres, never.
             const LeafGeo &G = A.leaf_geo[pi];
-            if (G.tag == 0) { // sphere.rs:39-59 / moving_sphere.rs:49-69 from the compact record
-                const d3 center = ld3(G.c0) + ((time - A.leaf_time_a) * A.leaf_inv_dt) * ld3(G.dc);
-                hit = sphere_t(center, G.radius2, o, d, inv_a, t_min, best_t, t);
-            } else {
-                hit = prim_t<PRIMS>(A.prims[pi], o, d, inv_d, inv_a, time, t_min, best_t, t, aux);
-            }
+            const long long tag = G.tag;
+            const d3 center = ld3(G.c0) + ((time - A.leaf_time_a) * A.leaf_inv_dt) * ld3(G.dc); // sphere.rs:39-59 / moving_sphere.rs:37-39,49-69
+            hit = sphere_t(center, G.radius2, o, d, inv_a, t_min, best_t, t) && tag == 0;
+            if (tag != 0) hit = prim_t<PRIMS>(A.prims[pi], o, d, inv_d, inv_a, time, t_min, best_t, t, aux);
             if (hit) {
                 best_t = t;
                 best = pi;

@@ -183,10 +183,9 @@ template <bool PREFETCH> __global__ __launch_bounds__(256, 4) void k_walk(const 
             if (walking) {
                 const uint4 *raw = reinterpret_cast<const uint4 *>(&nodes[i]);
                 const uint4 q0 = raw[0], q1 = raw[1];
-                const float mn[3] = {__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)};
-                const float mx[3] = {__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)};
+                const float lohi[6] = {__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z), __uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)};
                 const int skip = (int)q1.z, fc = (int)q1.w;
-                const bool hit = rtdev::slab_hit(mn, mx, sr, tmin_f, best_f, slack);
+                const bool hit = rtdev::slab_hit(lohi, sr, tmin_f, best_f);
                 i = hit ? i + 1 : skip;
                 count = hit ? (fc & 7) : 0;
                 first = fc >> 3;
@@ -354,10 +353,9 @@ __global__ __launch_bounds__(256, 4) void k_walk_donate(const Args A) {
                 if (walking) {
                     const uint4 *raw = reinterpret_cast<const uint4 *>(&nodes[i]);
                     const uint4 q0 = raw[0], q1 = raw[1];
-                    const float mn[3] = {__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)};
-                    const float mx[3] = {__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)};
+                    const float lohi[6] = {__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z), __uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)};
                     const int skip = (int)q1.z, fc = (int)q1.w;
-                    const bool hit = rtdev::slab_hit(mn, mx, sr, tmin_f, best_f, slack);
+                    const bool hit = rtdev::slab_hit(lohi, sr, tmin_f, best_f);
                     i = hit ? i + 1 : skip;
                     count = hit ? (fc & 7) : 0;
                     first = fc >> 3;

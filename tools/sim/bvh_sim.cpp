@@ -57,11 +57,11 @@ static bool hit_box(const rtdev::BvhNode &n, const double c[3], const Ray &r, do
     double t0 = 0.001;
     for (int k = 0; k < 3; ++k) { // entry distance in f64, for ordering children only
         const double inv = 1.0 / r.d[k];
-        const double a = ((double)n.mn[k] + c[k] - r.o[k]) * inv, b = ((double)n.mx[k] + c[k] - r.o[k]) * inv;
+        const double a = ((double)n.mn(k) + c[k] - r.o[k]) * inv, b = ((double)n.mx(k) + c[k] - r.o[k]) * inv;
         t0 = std::fmax(t0, std::fmin(a, b));
     }
     tnear = t0;
-    return rtdev::slab_hit(n.mn, n.mx, q.sr, q.tmin_f, best_f, slack);
+    return rtdev::slab_hit(n.lohi, q.sr, q.tmin_f, best_f);
 }
 static bool hit_prim(const RtPrimitive &p, const Ray &r, double tmax, double &t) {
     double c[3];
@@ -100,7 +100,7 @@ int main(int argc, char **argv) {
     rtdev::BvhBuild bvh = rtdev::build_bvh(d->primitives, d->n_primitives, max_leaf);
     g_bvh = &bvh;
     printf("max %d primitives per leaf: ", max_leaf);
-    const int n = (int)bvh.nodes.size();
+    const int n = (int)bvh.nodes.size() - 1; // the array ends with the walk's sentinel (rt_device_types.h: BvhNode), not a node of the tree
     Tree tree;
     tree.left.assign(n, -1);
     tree.right.assign(n, -1);
