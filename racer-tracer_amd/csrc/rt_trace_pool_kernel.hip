@@ -415,7 +415,7 @@ __device__ __noinline__ void deliver_item(const RT_CONSTANT TraceArgs *K_in, dou
             out[1] = sqrt(scale * acc1);
             out[2] = sqrt(scale * acc2);
         }
-        if (lane == 0) K->tile_done[tile_id] = 0u; // re-armed for the next launch on this scene
+        if (lane == 0) __hip_atomic_store(K->tile_done + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // re-armed for the next launch on this scene (written through, like the slices)
         // The pixels may sit in HOST memory: release them at system scope before this tile is counted (once per
         // tile, 1/19 of the items on C3), and publish the region behind an acquire of the other waves' releases.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
@@ -425,7 +425,7 @@ __device__ __noinline__ void deliver_item(const RT_CONSTANT TraceArgs *K_in, dou
         if (tiles_before == reg_tiles - 1u) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             if (lane == 0) {
-                K->region_done[region] = 0u;
+                __hip_atomic_store(K->region_done + region, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(K->deliver_flags + region, K->deliver_serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
@@ -913,7 +913,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                 }
             }
             RT_REGION(10); // Noise rounds
-            d3 sph; // only read by the lanes the sampler returns true for, which it has assigned
+            d3 sph = mk(0.0, 0.0, 0.0); // (left uninitialised, three moves fewer per iteration cost the plain variants 16 bytes of scratch)
             if (coop_random_in_unit_sphere(waiting, rng.pixel, rng.sample, seg, cand_base, A.seed_lo, A.seed_hi, lane,
                                            L.scratch.req, (TEXTURED || SPECULAR) ? 4 : 2, sph)) {
                 waiting = false;

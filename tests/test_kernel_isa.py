@@ -1,0 +1,76 @@
+"""What the hand-off inside the delivering launch rests on is in the GENERATED CODE, so it is pinned there (CPU test: hipcc
+cross-compiles gfx950 without a GPU).  deliver_item (csrc/rt_trace_pool_kernel.hip) passes a tile's per-chunk slices from
+the waves that wrote them to the wave that lands the tile's last chunk — waves of other XCDs, whose L2s are not coherent
+with each other — with device-scope RELAXED accesses and one s_waitcnt instead of a release / acquire fence per item
+(12 % of C2, profiles/r03_fence_probe.txt).  That is only sound if
+  * the slice stores carry sc1 (written through to the level all XCDs share) and an `s_waitcnt vmcnt(0)` stands between
+    them and the wave's bump of the tile counter,
+  * the slice loads of the finishing wave carry sc1 (they bypass a stale L2 line) and come after the counter's value has
+    returned (the atomic's own s_waitcnt vmcnt(0)),
+  * the finished pixels are released at system scope (buffer_wbl2 sc0 sc1) before the tile is counted for its region.
+The reference hands tiles over through a channel (cpu.rs:64-70); this is that channel's memory order."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def pool_kernel_asm(tmp_path_factory):
+    if not os.path.exists(HIPCC) and shutil.which("hipcc") is None:
+        pytest.skip("no hipcc")
+    out = str(tmp_path_factory.mktemp("isa") / "pool.s")
+    cmd = [HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "--cuda-device-only", "-S",
+           os.path.join(ROOT, "racer-tracer_amd", "csrc", "rt_trace_pool_kernel.hip"), "-o", out]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-2000:]
+    return open(out).read().split("\n")
+
+
+def function_body(lines, needle):
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN10rtdev_fast\d+" + needle + r"\w*:", l))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    return [l.strip() for l in lines[start:end] if l.startswith("\t") and not l.strip().startswith((".", ";"))]
+
+
+def test_deliver_item_hands_slices_over_with_sc1_and_waitcnt(pool_kernel_asm):
+    body = function_body(pool_kernel_asm, "deliver_item")
+    idx = lambda pred, after=0: next(i for i in range(after, len(body)) if pred(body[i]))
+    # 1. the three slice stores, device scope
+    stores = [i for i, l in enumerate(body) if l.startswith("global_store_dwordx2")][:3]
+    assert len(stores) == 3 and all("sc1" in body[i] for i in stores), [body[i] for i in stores]
+    # 2. ... acknowledged before the tile counter is bumped
+    wait = idx(lambda l: l.startswith("s_waitcnt") and "vmcnt(0)" in l, stores[-1])
+    bump = idx(lambda l: l.startswith("global_atomic_add"), stores[-1])
+    assert stores[-1] < wait < bump, body[stores[0]:bump + 1]
+    assert not any(l.startswith(("global_store", "global_load")) for l in body[wait:bump])
+    # 3. the finishing wave's slice loads: device scope, behind the counter's returned value
+    returned = idx(lambda l: l.startswith("s_waitcnt") and "vmcnt(0)" in l, bump)
+    loads = [i for i, l in enumerate(body) if l.startswith("global_load_dwordx2")]
+    assert len(loads) >= 3 and all("sc1" in body[i] for i in loads), [body[i] for i in loads]
+    assert all(i > returned for i in loads)
+    # 4. the pixels (plain stores, possibly to host memory) are released at system scope before the region is counted
+    pixels = max(i for i, l in enumerate(body) if l.startswith("global_store_dwordx") and "sc1" not in l)
+    release = idx(lambda l: l.startswith("buffer_wbl2") and "sc0" in l and "sc1" in l, pixels)
+    region_bump = idx(lambda l: l.startswith("global_atomic_add"), release)
+    assert pixels < release < region_bump
+    # 5. the counters' re-arming stores are written through as well
+    rearm = [l for l in body[loads[-1]:] if l.startswith("global_store_dword ")]
+    assert rearm and all("sc1" in l for l in rearm[:1]), rearm
+
+
+def test_no_scratch_in_the_plain_variants(pool_kernel_asm):
+    """The variants BASELINE configs 2 and 3 run keep their path state in registers: no private segment, and the
+    register count that six (five with specular materials) waves per SIMD need."""
+    text = "\n".join(pool_kernel_asm)
+    for variant, max_vgprs in (("Li0ELb0ELb0ELb0E", 80), ("Li1ELb0ELb0ELb0E", 80), ("Li0ELb0ELb1ELb0E", 96), ("Li1ELb0ELb1ELb0E", 96)):
+        m = re.search(r"\.amdhsa_kernel _ZN10rtdev_fast16k_trace_pool_f64I" + variant + r".*?\.end_amdhsa_kernel", text, re.S)
+        assert m, variant
+        vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(0)).group(1))
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(0)).group(1))
+        assert vgprs <= max_vgprs and scratch == 0, (variant, vgprs, scratch)
