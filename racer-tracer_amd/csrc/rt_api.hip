@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <cmath>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <string>
@@ -281,6 +282,33 @@ int rtapi::owned_rows_of(const RtRenderParams *p) {
     return owned_strips * p->strip_rows;
 }
 
+// What a pooled-kernel launch of these parameters needs in device memory, allocated now.  enqueue_render does the same
+// when it finds a buffer too small; a call over SEVERAL shares reserves for all of them before it launches the first
+// (rt_deliver.hip, rt_multi.hip): hipMalloc waits for the device's running kernels, so a share that allocated inside its
+// enqueue held the calling thread until the shares launched before it had finished — no cancel poll, no band copied
+// meanwhile (measured with two scenes on one card: 122 ms of a 4096-spp frame before the hook was looked at).
+int rtapi::reserve_render_buffers(RtScene *s, const RtRenderParams *p, bool delivering) {
+    if (s->use_v1) return RT_OK;
+    RT_HIP(hipSetDevice(s->device));
+    const int owned = p->scale > 1 ? p->height : owned_rows_of(p); // (the preview's grid is smaller: an upper bound)
+    const size_t slice_elems = (size_t)p->width * (size_t)owned * 3;
+    const size_t chunks = (size_t)chunk_plan(p->samples).size() - 1;
+    if (s->partial.count < slice_elems * chunks) RT_HIP(s->partial.alloc(slice_elems * chunks));
+    if (s->queue.count < 1) RT_HIP(s->queue.alloc(1));
+    if (delivering) {
+        const size_t n_tiles = (size_t)((p->width + 7) / 8) * (size_t)((owned + 7) / 8);
+        if (s->tile_done.count < n_tiles) {
+            RT_HIP(s->tile_done.alloc(n_tiles));
+            s->deliver_dirty = true;
+        }
+        if (s->region_done.count < (size_t)rtdev::RT_MAX_REGIONS) {
+            RT_HIP(s->region_done.alloc((size_t)rtdev::RT_MAX_REGIONS));
+            s->deliver_dirty = true;
+        }
+    }
+    return RT_OK;
+}
+
 int rtapi::enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, double *out_device,
                           hipStream_t stream, int batch, const Cancel &cancel, const Delivery *delivery, int out_col_step,
                           int out_cols) {
@@ -369,6 +397,11 @@ int rtapi::enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderPara
             a.deliver_col_step = delivery->col_step;
             a.deliver_cols = delivery->cols;
         }
+        // a call whose caller polls a cancel hook: the waves read the scene's cancel word with every item they fetch
+        if (cancel.armed() || (delivery && delivery->cancellable)) {
+            s->host_flags[rtdev::RT_MAX_REGIONS] = 0u;
+            a.cancel_flag = s->host_flags + rtdev::RT_MAX_REGIONS;
+        }
         const int n_batches = (int)plan.size();
         // slices hold the launch's owned rows only (the kernel compacts rows: owned_rows, tile_py0)
         a.slice_rows = a.owned_rows;
@@ -434,14 +467,26 @@ int rtapi::wait_event(hipEvent_t ev, const Cancel &cancel) {
     }
 }
 
-// Ends the pool launches of the current call early: every item counter of the call becomes 2^31
-// (enqueue_render keeps a launch below 2^30 items, so no count of further hand-outs wraps it).
-// The counters are written by the command processor (hipStreamWriteValue32 on a third stream): that needs
-// neither a compute unit nor a copy engine.  A 4-byte hipMemcpyAsync was measured first — the runtime runs it
-// as a kernel, which found no room beside six resident blocks per CU until the work in flight had finished
-// (50 ms instead of one item's 10).  The control stream first waits for ev_begin, which the render stream records
-// BEHIND its own clearing of the counters: a cancel raised right after the enqueue cannot be erased by that memset.
-int rtapi::poison_queue(RtScene *s) {
+// Ends the pool launches of the current call early.  Two ways at once:
+// * the scene's CANCEL WORD in pinned host memory (TraceArgs.cancel_flag), which the lane that fetches a wave's next item
+//   reads: a CPU store, seen by every wave at its next item — the way that always works;
+// * every item counter of the call becomes 2^31 (enqueue_render keeps a launch below 2^30 items, so no count of further
+//   hand-outs wraps it), written with hipStreamWriteValue32 on a third stream behind ev_begin (which the render stream
+//   records BEHIND its own clearing of the counters, so a cancel raised right after the enqueue cannot be erased).
+//   Rounds 2 and 3 relied on this one alone and took it for a command-processor write; it is a small kernel of the
+//   runtime's, which lands only while a SIMD has registers to spare: beside the 80-VGPR cornell variant (the one the
+//   cancel test rendered) within an item's time, beside a 128-VGPR variant — four waves x 128 = the whole file — or
+//   while another share's launch waits on the same device, not before the launch has ended (round 4 found it when the
+//   cancel tests began to count the rays a cancelled launch had started instead of taking its time).  It still covers
+//   the v1 kernel's launches and anything not yet started.
+int rtapi::poison_queue_begin(RtScene *s) {
+    // 1. the cancel word in pinned memory, which every wave reads with its next item: a CPU store, lands at once
+    if (s->host_flags) {
+        reinterpret_cast<volatile unsigned int *>(s->host_flags)[rtdev::RT_MAX_REGIONS] = 1u;
+        std::atomic_thread_fence(std::memory_order_seq_cst);
+    }
+    // 2. the item counters themselves, for a launch that has not started yet or a caller without the word (the v1
+    //    kernel's batches); this write is a small kernel of the runtime's and lands when it finds room
     RT_HIP(hipSetDevice(s->device));
     RT_HIP(hipStreamWaitEvent(s->stream_ctl, s->ev_begin, 0));
     bool by_cp = true;
@@ -451,10 +496,15 @@ int rtapi::poison_queue(RtScene *s) {
         (void)hipGetLastError();
         RT_HIP(hipMemsetD32Async((hipDeviceptr_t)s->queue.ptr, (int)0x80000000u, s->queue.count, s->stream_ctl));
     }
-    RT_HIP(hipStreamSynchronize(s->stream_ctl));
     return RT_OK;
 }
 
+int rtapi::poison_queue(RtScene *s) {
+    const int rc = poison_queue_begin(s);
+    if (rc != RT_OK) return rc;
+    RT_HIP(hipStreamSynchronize(s->stream_ctl));
+    return RT_OK;
+}
 
 // ---------------------------------------------------------------------------------------------- render-buffer cache
 // Everything a render call allocates on first use, kept per device across rt_scene_destroy / rt_scene_create.
@@ -905,9 +955,9 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
         RT_HIP(hipEventCreate(&s->ev_begin));
         RT_HIP(hipEventCreate(&s->ev_traced));
         RT_HIP(hipEventCreate(&s->ev_resolved));
-        RT_HIP(hipHostMalloc((void **)&s->host_flags, rtdev::RT_MAX_REGIONS * sizeof(unsigned int),
+        RT_HIP(hipHostMalloc((void **)&s->host_flags, (rtdev::RT_MAX_REGIONS + 1) * sizeof(unsigned int),
                              hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
-        memset(s->host_flags, 0, rtdev::RT_MAX_REGIONS * sizeof(unsigned int));
+        memset(s->host_flags, 0, (rtdev::RT_MAX_REGIONS + 1) * sizeof(unsigned int));
         RT_HIP(hipStreamCreateWithFlags(&s->stream_ctl, hipStreamNonBlocking));
     }
     RT_HIP(hipMemsetAsync(s->segments.ptr, 0, rtdev::RT_STAT_SLOTS * sizeof(unsigned long long), s->stream));

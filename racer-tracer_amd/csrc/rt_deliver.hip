@@ -84,11 +84,12 @@ int wait_region(Share &sh, int r, const Cancel &cancel) {
 
 // Ends everything in flight (cancel or error) and leaves the scenes reusable.
 void abort_shares(std::vector<Share> &shares) {
-    for (Share &sh : shares)
-        if (sh.launched) (void)rtapi::poison_queue(sh.scene);
+    for (Share &sh : shares) // every share's poison is on its way before any of them is waited for
+        if (sh.launched) (void)rtapi::poison_queue_begin(sh.scene);
     for (Share &sh : shares)
         if (sh.launched) {
             (void)hipSetDevice(sh.scene->device);
+            (void)hipStreamSynchronize(sh.scene->stream_ctl);
             (void)hipStreamSynchronize(sh.scene->stream);
         }
     (void)hipGetLastError();
@@ -139,8 +140,14 @@ int make_shares(RtScene *const *scenes, int n, const RtRenderParams *p, int stri
     return RT_OK;
 }
 
-int launch_shares(std::vector<Share> &shares, const RtCamera *camera) {
+int launch_shares(std::vector<Share> &shares, const RtCamera *camera, bool cancellable = false) {
+    for (Share &sh : shares) { // every allocation of the call before its first launch (rt_api.hip: reserve_render_buffers)
+        if (sh.delivery.regions.empty()) continue;
+        const int rc = rtapi::reserve_render_buffers(sh.scene, &sh.params, true);
+        if (rc != RT_OK) return rc;
+    }
     for (Share &sh : shares) {
+        sh.delivery.cancellable = cancellable;
         // A share that owns no rows (more shares than strips: height 16 over three scenes; a strip_index whose first
         // strip lies below the image) has nothing to launch and nothing to wait for: it counts as published, and the
         // rows of the frame stay as they are — what the two-pass path does with n_items == 0.
@@ -290,7 +297,7 @@ int deliver_tiles(RtScene *const *scenes, int n, const RtCamera *camera, const R
         sh.delivery.col_step = width_step;
         sh.delivery.cols = p->tiles_w;
     }
-    rc = launch_shares(shares, camera);
+    rc = launch_shares(shares, camera, cancel.armed());
     bool cancelled = false;
     int emitted = 0;
     for (size_t r = 0; r < regions.size() && rc == RT_OK && !cancelled; ++r) {

@@ -171,6 +171,12 @@ struct TraceArgs {
     double *partial;             // [n_chunks_total][slice_rows][width][3]: the rows of the launch's OWNED-row grid only
     int32_t slice_rows;          // rows per slice = owned_rows (a rank's eighth of a C5 frame keeps 0.53 GB of slices, not 4.2)
     unsigned int *queue;         // item counter (zeroed before the launch)
+    // CANCEL.  A word in pinned host memory (or NULL when the call cannot be cancelled): the lane that fetches a wave's
+    // next item also reads it, and non-zero means "the queue is dry".  The host raises it with a plain store — no
+    // command-processor packet, no fill kernel, nothing that has to find room on a GPU that a persistent grid fills:
+    // hipStreamWriteValue32 turned out to be a blit KERNEL, which only lands while a SIMD has registers to spare (it
+    // never did beside the 128-VGPR variants, nor while another share's launch waited on the same device).
+    const unsigned int *cancel_flag;
     uint32_t n_items;
     int32_t n_chunks;            // chunks in this launch
     int32_t chunk_base;          // index of this launch's first chunk in `partial`

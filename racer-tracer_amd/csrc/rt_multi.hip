@@ -60,8 +60,7 @@ int render_multi(RtScene *const *scenes, int n, const RtCamera *camera, const Rt
                 if (hipSetDevice(s->device) == hipSuccess) (void)hipStreamSynchronize(s->stream);
         }
     } drain;
-    // 1. every device starts tracing before any copy is enqueued (a copy to pageable host memory
-    //    blocks the calling thread)
+    // 0. every allocation of the call before its first launch (hipMalloc waits for the device's running kernels)
     for (int i = 0; i < n; ++i) {
         Share &sh = shares[(size_t)i];
         sh.scene = scenes[i];
@@ -72,15 +71,19 @@ int render_multi(RtScene *const *scenes, int n, const RtCamera *camera, const Rt
             sh.params.strip_index = i;
         }
         RT_HIP(hipSetDevice(sh.scene->device));
+        sh.in_place = sh.scene->device == dst_device && !sh.scene->gather_staged;
+        if (!sh.in_place && sh.scene->frame.count < n_elems) RT_HIP(sh.scene->frame.alloc(n_elems));
+        rc = rtapi::reserve_render_buffers(sh.scene, &sh.params, false);
+        if (rc != RT_OK) return rc;
+    }
+    // 1. every device starts tracing before any copy is enqueued (a copy to pageable host memory
+    //    blocks the calling thread)
+    for (int i = 0; i < n; ++i) {
+        Share &sh = shares[(size_t)i];
+        RT_HIP(hipSetDevice(sh.scene->device));
         // RT_GATHER_STAGED (RtSceneOptions.gather, a test switch): the share renders into its own staging frame and is
         // copied even when it sits on the output's device, so that ONE card runs what several run
-        sh.in_place = sh.scene->device == dst_device && !sh.scene->gather_staged;
-        if (sh.in_place) {
-            sh.target = out;
-        } else {
-            if (sh.scene->frame.count < n_elems) RT_HIP(sh.scene->frame.alloc(n_elems));
-            sh.target = sh.scene->frame.ptr;
-        }
+        sh.target = sh.in_place ? out : sh.scene->frame.ptr;
         rc = rtapi::enqueue_render(sh.scene, camera, &sh.params, sh.target, sh.scene->stream, 0, rtapi::Cancel());
         drain.launched.push_back(sh.scene);
         if (rc != RT_OK) return rc;

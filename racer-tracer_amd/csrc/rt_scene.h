@@ -54,6 +54,7 @@ struct Delivery {
     int col_step = 0, cols = 1;         // tile-column layout; cols == 1: plain [H][W][3] with col_step == width
     std::vector<rtdev::Region> regions; // non-empty rectangles of item tiles in queue order (item_begin is filled in)
     uint32_t serial = 0;                // value published in the scene's host_flags[region]
+    bool cancellable = false;           // the caller polls a cancel hook while this launch runs: the waves read the scene's cancel word
 };
 
 } // namespace rtapi
@@ -107,7 +108,7 @@ struct RtScene {
     // in `host_flags`; tile_done / region_done are the device counters behind that (zero between launches).
     double *host_frame = nullptr;
     size_t host_frame_count = 0;
-    unsigned int *host_flags = nullptr; // [RT_MAX_REGIONS]
+    unsigned int *host_flags = nullptr; // [RT_MAX_REGIONS] published regions + [1] the cancel word the waves read (TraceArgs.cancel_flag)
     rtapi::DevBuf<unsigned int> tile_done, region_done;
     uint32_t deliver_serial = 0;
     bool deliver_dirty = false; // a delivering launch was cut short: the counters must be cleared before the next one
@@ -128,10 +129,16 @@ int check_params(const RtCamera *camera, const RtRenderParams *p);
 int enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderParams *p, double *out_device,
                    hipStream_t stream, int batch, const Cancel &cancel, const Delivery *delivery = nullptr,
                    int out_col_step = 0, int out_cols = 1);
+// Allocate now what enqueue_render would allocate for these parameters (calls over several shares: before the first launch).
+int reserve_render_buffers(RtScene *s, const RtRenderParams *p, bool delivering);
 // Block until `ev` has happened, polling `cancel` meanwhile (RT_ERR_CANCEL_EVENT as soon as it is raised).
 int wait_event(hipEvent_t ev, const Cancel &cancel);
 // Ends the pool launches in flight on `s` early: every item counter becomes 2^31 (rt_api.hip).
 int poison_queue(RtScene *s);
+// The same without waiting for the write to land: several shares are poisoned side by side (rt_deliver.hip: abort_shares) —
+// a share whose launch still waits behind another share's on the SAME device only reaches its ev_begin when that one ends,
+// and waiting for it before poisoning the next would let the next run to its end.
+int poison_queue_begin(RtScene *s);
 // Image row of row `vr` of the launch's owned-row grid (identity without strips).
 inline int owned_row_to_image_row(const RtRenderParams *p, int vr) {
     if (p->strip_count <= 1) return vr;

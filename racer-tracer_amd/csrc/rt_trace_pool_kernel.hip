@@ -513,7 +513,13 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
     for (;;) {
         // ---- next item for this wave
         uint32_t item = 0;
-        if (lane == 0) item = atomicAdd(A.queue, 1u);
+        if (lane == 0) {
+            item = atomicAdd(A.queue, 1u);
+            // the host's cancel word (rt_device_types.h: cancel_flag): one uncached read of pinned memory per item and wave,
+            // in flight together with the atomic; raised = no more items for this wave
+            const unsigned int *cf = kernargs_here()->cancel_flag;
+            if (cf != nullptr && __hip_atomic_load(cf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) item = 0x80000000u;
+        }
         item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
         if (item >= A.n_items) break;
         // item -> (region, chunk, tile): regions in queue order, chunk-major inside a region (rt_device_types.h: Region)

@@ -185,7 +185,9 @@ def test_tile_stream_over_several_scenes_on_one_card(rt, gpu):
         timer.join()
         print("rt_render_multi (2 shares) returned %.1f ms after the call began" % ((time.time() - t0) * 1e3))
         started = sum(int(sc.last_stats().samples) for sc in scenes[:2])
-        assert len(tiles) < 100 and started < 1920 * 1080 * 4096    # cut short on both shares (device-counted), a prefix delivered
+        # counted on the device: the share that was running stopped within an item's time of the hook (it had started
+        # under half of its rays), the one still waiting behind it on this one card started none
+        assert len(tiles) < 100 and started < 0.5 * 1920 * 1080 * 4096
         after = rt.render_tiles_multi(scenes[:2], camera, params)
         for got, want in zip(after, want_tiles):
             assert np.array_equal(got[4], want[4])
@@ -194,6 +196,41 @@ def test_tile_stream_over_several_scenes_on_one_card(rt, gpu):
     finally:
         for s in scenes:
             s.close()
+
+
+def test_cancel_reaches_a_launch_that_fills_the_register_file(rt, gpu):
+    """The textured variants run four waves of 128 VGPRs per SIMD: nothing else fits on the GPU while they run.  The
+    cancel must not depend on anything finding room there (rounds 2-3 wrote the item counters with
+    hipStreamWriteValue32, a small kernel of the runtime's: it landed when the launch was over); the waves read a word in
+    pinned host memory instead (TraceArgs.cancel_flag).  noise_and_textures at 4096 spp is ~0.42 s of GPU work; the hook
+    rises from the first tile's callback and the launch must have started well under half of its rays (counted on the
+    device) — like do_cancel stopping the reference's tile loop (renderer.rs:25-30, cpu.rs:55-62)."""
+    import importlib
+    import os
+    host = importlib.import_module("racer-tracer_amd.host")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    session = host.Session(os.path.join(root, "scenes", "config_c4.yml"), scene=os.path.join(root, "scenes", "noise_and_textures.yml"))
+    p = session.params
+    p.samples = 4096
+    total = p.width * p.height * p.samples
+    scene = rt.Scene(session)
+    try:
+        scene.render_frame(session.camera, S.abi.render_params(p.width, p.height, 1))   # allocations out of the way
+        flag = C.c_int(0)
+        tiles = []
+
+        def on_tile(_user, rgb, r, c, tw, th):
+            tiles.append((r, c))
+            flag.value = 1
+
+        cb = S.abi.RtTileCallback(on_tile)
+        t0 = time.time()
+        rt.check(rt.lib().rt_render(scene._h, C.byref(session.camera), C.byref(p), cb, None, C.pointer(flag)), "rt_render")
+        started = int(scene.last_stats().samples)
+        print("noise_and_textures: rt_render returned after %.1f ms with %.1f %% of the primary rays started" % ((time.time() - t0) * 1e3, 100.0 * started / total))
+        assert len(tiles) == 1 and 0.10 * total <= started < 0.30 * total
+    finally:
+        scene.close()
 
 
 def test_whole_frame_over_several_scenes_matches(rt, gpu):
