@@ -447,7 +447,7 @@ __device__ __forceinline__ bool box_t(const Prim &P, d3 o, d3 d, d3 inv_d, doubl
 // "while-while" shape: every lane first walks inner nodes until it stands on a
 // leaf whose box it hits (or has left the tree), THEN the wave tests leaf
 // primitives together.  Mixing the two in one loop body makes a wave pay the
-// primitive tests on almost every step (measured 1.35 -> see DESIGN.md).
+// primitive tests on almost every step (measured: LABNOTES.md, round-3 section 4.6).
 struct NoMark { // profile hook of closest_hit_bvh: the regions build passes one that books cycles
     __device__ __forceinline__ void operator()(int) const {}
 };

@@ -55,7 +55,7 @@
 //    direction (the incoming one is dead), and a finished path's contribution is formed in the throughput.  Every
 //    value kept beside those cost registers and, where the material arms meet, a copy per arm.
 //
-// The launch is VALU-throughput bound (DESIGN.md 4.2 has the counters, the per-region
+// The launch is VALU-throughput bound (DESIGN.md 4.2 / 6 and LABNOTES.md have the counters, the per-region
 // cycle profile of the -DRT_PROFILE_REGIONS build, and the variants that were measured and
 // dropped).
 #include <cstddef>
