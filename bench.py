@@ -527,13 +527,17 @@ def main():
         if args.force_dist:
             out["force_dist"] = "backend %s, world %d: process group initialised, strips gathered with dist.gather" % (
                 dist.get_backend(), world)
-        if rehearsal or args.force_dist:
-            # the gathered frame must equal a single-rank render of the same frame
+        if dist is not None:
+            # whenever a collective assembled the frame: it must equal a single-rank render of the same frame, bit for bit
+            # (outside the timed region; on a real multi-GPU node this is the first evidence that N ranks + RCCL deliver
+            # the frame one GPU renders — the strips are keyed by global pixel index, section 5 of DESIGN.md)
             p.strip_count = 0
             whole = torch.zeros_like(frame)
             scene.render_frame_device(session.camera, p, whole.data_ptr(), stream.cuda_stream)
             torch.cuda.synchronize()
-            out["rehearsal_frame_matches_single_rank"] = bool(torch.equal(whole, frame))
+            out["gathered_frame_matches_single_rank"] = bool(torch.equal(whole, frame))
+            if rehearsal or args.force_dist:
+                out["rehearsal_frame_matches_single_rank"] = out["gathered_frame_matches_single_rank"]
         print(json.dumps(out), flush=True)
     scene.close()
     if dist is not None:
