@@ -515,10 +515,17 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
         uint32_t item = 0;
         if (lane == 0) {
             item = atomicAdd(A.queue, 1u);
-            // the host's cancel word (rt_device_types.h: cancel_flag): one uncached read of pinned memory per item and wave,
-            // in flight together with the atomic; raised = no more items for this wave
+            // The host's cancel word (rt_device_types.h: cancel_flag).  Reads of pinned host memory are a scarce resource —
+            // every item of every wave asking cost rt_render 30 % on C3 (615 000 items, ~28 M such reads per second is
+            // what the link gives) — so only the wave that draws an item whose number is a multiple of 32 asks, and when
+            // the word is up it poisons the launch's item counter ITSELF: every other wave's next atomicAdd then returns
+            // "queue dry".  On C3 an item is drawn every 0.12 us, so somebody asks every 4 us.
             const unsigned int *cf = kernargs_here()->cancel_flag;
-            if (cf != nullptr && __hip_atomic_load(cf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) item = 0x80000000u;
+            if (cf != nullptr && (item & 31u) == 0u && item < A.n_items &&
+                __hip_atomic_load(cf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
+                atomicOr(A.queue, 0x80000000u);
+                item = 0x80000000u;
+            }
         }
         item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
         if (item >= A.n_items) break;

@@ -8,6 +8,8 @@
 # 4. region / lane profile of the -DRT_PROFILE_REGIONS build (if it has been built: make -C racer-tracer_amd profile-lib)
 # 5. the `random` scene through the BVH and the linear loop, every shipped scene, C5 on one card, per-rank shares
 # 6. bench.py's N > 1 path on one card: the gloo rehearsal with 2 ranks, and RCCL with one rank (--force-dist)
+# Second call (the box's time limit): tools/gpu_finalize_more.sh <round> — kernel statistics of the other workloads, the
+# sustained run, seeds, executed-opcode histograms, scene-create latency, the 4- and 5-rank rehearsals.
 # Copy gpurun_out/<round>/<round>_* into profiles/ afterwards.
 set -o pipefail
 round=${1:-r03}
@@ -20,7 +22,7 @@ for w in c3 c2 c4 random boxes emissive; do
   rm -rf "$out/${round}_${w}_pmc_summary_passes"
   echo "pmc $w done"
 done
-for w in c3 c2 c4; do
+for w in c3 c2 c4 boxes emissive random; do
   extra="--no-cpu-baseline"; [ $w == c3 ] && extra=""
   timeout -k 10 400 python3 bench.py --workload $w $extra > "$out/${round}_${w}_bench.json" 2> "$out/bench_$w.err" || { tail -5 "$out/bench_$w.err"; exit 1; }
   python3 -c "
@@ -35,7 +37,7 @@ cp "$f" "$out/${round}_c3_kernel_stats.csv"
 sed -n 1,6p "$out/${round}_c3_kernel_stats.csv"
 rm -rf "$out/prof_c3"
 if [ -f racer-tracer_amd/build/libracer_tracer_amd_regions.so ]; then
-  timeout -k 10 300 tools/region_profile.sh c3 c2 c4 > "$out/${round}_region_cycles.txt" 2>&1
+  timeout -k 10 400 tools/region_profile.sh c3 c2 c4 boxes random > "$out/${round}_region_cycles.txt" 2>&1
   grep -c region "$out/${round}_region_cycles.txt"
 fi
 timeout -k 10 300 python3 tools/perf_random.py 64 2>&1 | grep -v amdgpu.ids | tee "$out/${round}_random_scene.txt"
