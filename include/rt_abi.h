@@ -369,8 +369,9 @@ typedef int (*RtCancelCallback)(void *cancel_user);
 
 /* Replaces `CpuRenderer::render` with the reference's own tile stream:
  * tiles_w x tiles_h tiles in column-major order with the last row/column
- * absorbing remainders (cpu.rs:73-115), one callback per tile, on the
- * calling thread.  Delivery is progressive: ONE launch renders the frame tile
+ * absorbing remainders (cpu.rs:73-115), one callback per tile — tiles_w *
+ * tiles_h of them, an empty tile (more tile rows than image rows) included,
+ * with width or height 0 — on the calling thread.  Delivery is progressive: ONE launch renders the frame tile
  * column by tile column and writes finished pixels straight into pinned host
  * memory; the callbacks of a finished column run while the GPU works on the
  * next, so tiles arrive during the render as the reference's do (cpu.rs:64-70);

@@ -96,7 +96,8 @@ def render_frame_multi_device(scenes, camera, params, out_ptr, strip_rows=0):
 
 def _tile_collector(tiles):
     def on_tile(_user, rgb, r, c, w, h):
-        arr = np.ctypeslib.as_array(rgb, shape=(h, w, 3)).copy()  # `rgb` is only valid during the callback
+        # `rgb` is only valid during the callback; an empty tile (more tile rows / columns than pixels) carries no pixels
+        arr = np.ctypeslib.as_array(rgb, shape=(h, w, 3)).copy() if w > 0 and h > 0 else np.zeros((h, w, 3))
         tiles.append((r, c, w, h, arr))
     return on_tile
 

@@ -252,8 +252,9 @@ int deliver_tiles(RtScene *const *scenes, int n, const RtCamera *camera, const R
             if (cancel.raised()) return false;
             const int y = height_step * hs;
             const int h = hs == p->tiles_h - 1 ? p->height - y : height_step;
-            if (w <= 0 || h <= 0) continue;
-            callback(user, col + (size_t)y * (size_t)w * 3, y, x, w, h);
+            // (an empty tile — more tile rows than image rows — is still ONE BufferUpdate, as in the reference, whose
+            // raytrace sends the buffer of every SubImage, empty or not: cpu.rs:64-70)
+            callback(user, col + (size_t)y * (size_t)(w > 0 ? w : 0) * 3, y, x, w > 0 ? w : 0, h > 0 ? h : 0);
         }
         return true;
     };
@@ -344,9 +345,15 @@ int tiles_from_frame(RtScene *s, const RtCamera *camera, const RtRenderParams *p
     const bool column_layout = !s->use_v1 && width_step > 0 && p->tiles_w > 1; // written by the resolve pass itself
     rc = rtapi::enqueue_render(s, camera, p, s->frame.ptr, s->stream, batch, cancel, nullptr, column_layout ? width_step : 0,
                                column_layout ? p->tiles_w : 1);
-    if (rc == RT_OK) RT_HIP(hipMemcpyAsync(s->host_frame, s->frame.ptr, n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     hipEvent_t copied = s->ev_resolved; // re-recorded behind the copy: rt_scene_last_stats reads ev_traced -> ev_resolved (+ the copy)
-    if (rc == RT_OK) RT_HIP(hipEventRecord(copied, s->stream));
+    if (rc == RT_OK) {
+        hipError_t e = hipMemcpyAsync(s->host_frame, s->frame.ptr, n * sizeof(double), hipMemcpyDeviceToHost, s->stream);
+        if (e == hipSuccess) e = hipEventRecord(copied, s->stream);
+        if (e != hipSuccess) { // the kernels are in flight on the scene's buffers: drain before the error goes up
+            (void)hipStreamSynchronize(s->stream);
+            return fail(RT_ERR_HIP, std::string("tiles_from_frame: ") + hipGetErrorString(e));
+        }
+    }
     if (rc == RT_OK) rc = rtapi::wait_event(copied, cancel);
     if (rc == RT_ERR_CANCEL_EVENT) { // cpu.rs:55-62: return Ok, no tile written
         rc = s->use_v1 ? RT_OK : rtapi::poison_queue(s);
@@ -361,12 +368,11 @@ int tiles_from_frame(RtScene *s, const RtCamera *camera, const RtRenderParams *p
     std::vector<double> column; // v1 / single-column grids: one column of the plain frame, repacked
     for (int ws = 0; ws < p->tiles_w; ++ws) {
         const int x = width_step * ws, w = ws == p->tiles_w - 1 ? p->width - x : width_step;
-        if (w <= 0) continue;
         const double *col;
         if (column_layout) {
             col = s->host_frame + (size_t)p->height * (size_t)x * 3;
-        } else if (w == p->width) {
-            col = s->host_frame;
+        } else if (w == p->width || w <= 0) {
+            col = s->host_frame; // (w == 0: an empty tile column — more tile columns than pixels — reads nothing)
         } else {
             column.resize((size_t)w * (size_t)p->height * 3);
             for (int r = 0; r < p->height; ++r)
@@ -377,8 +383,7 @@ int tiles_from_frame(RtScene *s, const RtCamera *camera, const RtRenderParams *p
             if (cancel.raised()) return RT_OK;
             const int y = height_step * hs;
             const int h = hs == p->tiles_h - 1 ? p->height - y : height_step;
-            if (h <= 0) continue;
-            callback(user, col + (size_t)y * (size_t)w * 3, y, x, w, h);
+            callback(user, col + (size_t)y * (size_t)(w > 0 ? w : 0) * 3, y, x, w > 0 ? w : 0, h > 0 ? h : 0); // empty tiles are sent too (cpu.rs:64-70)
         }
     }
     return RT_OK;

@@ -232,12 +232,13 @@ def test_cancel_during_render_returns_ok_and_stops_the_tile_stream(rt, orc, gpu)
         scene.close()
 
 
-@pytest.mark.parametrize("w,h,tw,th", [(101, 47, 7, 3), (64, 36, 2, 2), (50, 30, 1, 4), (37, 23, 10, 10), (9, 9, 12, 2)])
+@pytest.mark.parametrize("w,h,tw,th", [(101, 47, 7, 3), (64, 36, 2, 2), (50, 30, 1, 4), (37, 23, 10, 10), (9, 9, 12, 2), (20, 5, 2, 8)])
 def test_progressive_tiles_are_bit_identical_to_the_frame(rt, orc, gpu, w, h, tw, th):
     """Tile columns are regions of ONE delivering launch (column windows of the item grid,
     racer-tracer_amd/csrc/rt_deliver.hip) and are handed over while the next column renders;
     every pixel must still be the whole-frame render's pixel bit for bit, in cpu.rs:73-115's
-    order, with and without a cancel flag."""
+    order, with and without a cancel flag.  Empty tiles (a grid with more rows or columns than the image has pixels)
+    are sent too, as empty BufferUpdates: the reference's raytrace sends every SubImage's buffer (cpu.rs:64-70)."""
     import ctypes as C
     bundle, cam, _ = S.cornell_box_boxes()
     spp = 40
@@ -256,9 +257,8 @@ def test_progressive_tiles_are_bit_identical_to_the_frame(rt, orc, gpu, w, h, tw
                 for hs in range(th):
                     tile_w = w - ws_step * ws if ws == tw - 1 else ws_step
                     tile_h = h - hs_step * hs if hs == th - 1 else hs_step
-                    if tile_w > 0 and tile_h > 0:
-                        expect.append((hs_step * hs, ws_step * ws, tile_w, tile_h))
-            assert [t[:4] for t in tiles] == expect
+                    expect.append((hs_step * hs, ws_step * ws, max(tile_w, 0), max(tile_h, 0)))
+            assert [t[:4] for t in tiles] == expect and len(tiles) == tw * th
             stitched = np.full_like(frame, -1.0)
             for r, c, tile_w, tile_h, arr in tiles:
                 stitched[r:r + tile_h, c:c + tile_w] = arr
