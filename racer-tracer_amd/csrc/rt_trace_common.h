@@ -763,6 +763,18 @@ __device__ __forceinline__ int sin_sign(double x) {
 // of k — instead of three -1/0/+1 integers built with compares and selects and then multiplied (18 vector instructions
 // per factor, 12 now; the same predicate, so the same texture side for every point).
 __device__ __forceinline__ bool sines_product_negative(double a, double b, double c) {
+#ifndef RT_EXACT_DIV
+    // sin(x) < 0 exactly when floor(x / pi) is odd, and sin(x) = 0 for a double x only at x = 0: the predicate is the
+    // parity of three floors.  x * (1 / pi) in one rounded product is off by 2^-52 relative, so it names the wrong
+    // half-period only for an x within |x| 2.2e-16 of a multiple of pi — for the |x| <= 1e4 of a checkered surface a
+    // chance of 1e-12 per factor, where the three-term Cody-Waite reduction below is exact to 1e-21 k.  That buys 35 of the
+    // 53 vector instructions this test ran on EVERY iteration of noise_and_textures (its ground is the checker):
+    // 4.3 % of C4's vector instructions (profiles/r04_c4_opcode_hist.txt).  RT_ARITH_REFERENCE keeps the reduction.
+    const double inv_pi = 0.31830988618379067154;
+    const uint32_t odd = (uint32_t)(int)floor(a * inv_pi) ^ (uint32_t)(int)floor(b * inv_pi) ^ (uint32_t)(int)floor(c * inv_pi);
+    const bool zero = a * b * c == 0.0; // a factor sin(0) = 0 makes the product 0, which is not < 0 (|x| < 1e-100 aside)
+    return !zero && (odd & 1u) != 0u;
+#else
     uint32_t negative = 0;
     bool zero = false;
     const double xs[3] = {a, b, c};
@@ -778,6 +790,7 @@ __device__ __forceinline__ bool sines_product_negative(double a, double b, doubl
         negative ^= (q >> 1) ^ (~q & r_neg); // bit 0: this factor is negative (when it is not zero)
     }
     return !zero && (negative & 1u) != 0u;
+#endif
 }
 
 // Texture::value for everything that is not a plain SolidColor.
