@@ -78,6 +78,27 @@ def valu_class(op):
     return "other"
 
 
+def issue_cycles(op):
+    """SIMD cycles a wave instruction of this opcode holds the vector pipe, as measured on gfx950
+    (tools/microbench/valu_cost.hip, profiles/r02_valu_cost.txt): plain 32-bit VOP1/VOP2 2.3; f64 arithmetic, every
+    compare, v_cndmask, 64-bit moves and shifts, 32-bit multiplies, v_mad_u64_u32, three-operand integer ops, packed
+    f32, lane ops 4.2; f64 rcp / rsq / sqrt 16; f32 transcendentals 8."""
+    o = short(op)
+    if o in ("v_rcp_f64", "v_rsq_f64", "v_sqrt_f64"):
+        return 16.0
+    if re.match(r"v_(rcp|rsq|sqrt|sin|cos|exp|log)_f32", o):
+        return 8.0
+    if o.startswith(("v_cmp", "v_cndmask", "v_pk_", "v_mad_", "v_mul_lo", "v_mul_hi", "v_mbcnt", "v_readlane", "v_writelane", "v_readfirstlane",
+                     "v_add3", "v_lshl_add", "v_add_lshl", "v_and_or", "v_lshl_or", "v_or3", "v_xad", "v_bfi", "v_alignbit", "v_perm", "v_med3",
+                     "v_min3", "v_max3", "v_div_fixup", "v_ldexp", "v_fma_f64", "v_fmac_f64", "v_mul_u32_u24", "v_mul_hi_u32_u24", "v_mad_u32_u24")):
+        return 4.2
+    if o.endswith(("_f64", "_b64", "_u64", "_i64")):
+        return 4.2
+    if o == "v_bitop3_b32" or o.startswith(("v_fma_f32", "v_fmac_f32", "v_min_f32", "v_max_f32", "v_mul_f32", "v_add_f32", "v_sub_f32")):
+        return 2.5
+    return 2.3
+
+
 def source_text(cache, where):
     if not where:
         return ""
@@ -106,7 +127,7 @@ def function_of(cache, fcache, where):
     lines = cache.get(f, [])
     name = f
     for i in range(min(int(n), len(lines)) - 1, -1, -1):
-        m = re.match(r"^(?:template\s*<[^>]*>\s*)?(?:__device__|__global__|static|inline|__forceinline__|__noinline__|\s)*[\w:<>,\s\*&]*?\b(operator\s*[-+*/]|\w+)\s*\([^;]*$", lines[i])
+        m = re.match(r"^(?:template\s*<[^>]*>\s*)?[\w:<>,\s\*&]*?\b(operator\s*[-+*/]|\w+)\s*\([^;{]*(?:\)\s*(?:const\s*)?\{.*)?$", lines[i])
         if m and not lines[i].startswith((" ", "\t", "#", "//")) and m.group(1) not in ("if", "for", "while", "switch", "return", "defined"):
             name = "%s: %s" % (f, m.group(1))
             break
@@ -168,6 +189,9 @@ def main():
     by_line_valu = collections.Counter()
     by_func = collections.Counter()
     by_func_valu = collections.Counter()
+    cyc_line = collections.Counter()
+    cyc_func = collections.Counter()
+    cyc_op = collections.Counter()
     cache, fcache = {}, {}
     for b in blocks["blocks"]:
         c = counts[b["id"]]
@@ -181,6 +205,10 @@ def main():
                 by_class[valu_class(op)] += c
                 by_line_valu[where] += c
                 by_func_valu[function_of(cache, fcache, where)] += c
+                cy = c * issue_cycles(op)
+                cyc_line[where] += cy
+                cyc_func[function_of(cache, fcache, where)] += cy
+                cyc_op[short(op)] += cy
             if u != "other":
                 by_line[where] += c
                 by_func[function_of(cache, fcache, where)] += c
@@ -233,6 +261,19 @@ def main():
         if rest:
             emit("  %-28s %14.6g  %6.2f %%" % ("(opcodes below 0.2 %)", rest, 100.0 * rest / tot))
         emit()
+    total_cyc = float(sum(cyc_op.values())) or 1.0
+    emit("vector ISSUE CYCLES (instructions x the measured cost of their opcode, tools/microbench/valu_cost.hip): %.4g per launch, %.1f per segment"
+         % (total_cyc, total_cyc / segs))
+    emit("  by opcode (share of the cycles)")
+    for op, cy in cyc_op.most_common(25):
+        emit("  %-28s %6.2f %%  %8.3f cycles / segment" % (op, 100.0 * cy / total_cyc, cy / segs))
+    emit("  by source function")
+    for f, cy in cyc_func.most_common(25):
+        emit("  %-44s %6.2f %%  %8.3f" % (f, 100.0 * cy / total_cyc, cy / segs))
+    emit("  by source line, top 40")
+    for where, cy in cyc_line.most_common(40):
+        emit("  %-26s %6.2f %%  %8.3f   %s" % (where or "(no line)", 100.0 * cy / total_cyc, cy / segs, source_text(cache, where)))
+    emit()
     emit("vector instructions by source function (share of the vector instructions, per segment)")
     for f, c in by_func_valu.most_common(30):
         emit("  %-44s %14.6g  %6.2f %%  %8.4f" % (f, c, 100.0 * c / total_valu, c / segs))
