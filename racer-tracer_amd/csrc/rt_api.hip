@@ -248,6 +248,7 @@ void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtd
     a.accum = s->accum.ptr;
     a.segments = s->segments.ptr;
     a.bvh_nodes = s->bvh_nodes.ptr;
+    a.bvh_nodes_ordered = s->bvh_nodes_in_lds ? nullptr : s->bvh_nodes_ordered.ptr;
     a.bvh_prim_index = s->bvh_prim_index.ptr;
     a.n_bvh_nodes = s->n_bvh_nodes;
     for (int k = 0; k < 3; ++k) {
@@ -682,6 +683,7 @@ void rt_scene_destroy(RtScene *s) {
     s->images.release();
     s->perlins.release();
     s->bvh_nodes.release();
+    s->bvh_nodes_ordered.release();
     s->bvh_prim_index.release();
     s->leaf_geo.release();
     // what a render allocates — slices, frames, pinned memory, counters, streams, events — outlives the scene: the
@@ -867,7 +869,10 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
             const size_t bytes = b.nodes.size() * sizeof(rtdev::BvhNode);
             return (s->exact ? rtdev_pool_blocks_per_cu_exact : rtdev_pool_blocks_per_cu)(s->prims_class, s->textured, s->specular, 1, (bytes <= 32 * 1024 ? bytes : 0) + lds_other);
         };
-        rtdev::BvhBuild bvh = rtdev::build_bvh(d->primitives, d->n_primitives, 4);
+        // (more than 2048 primitives: at most four to a leaf, the node array cannot fit LDS — the direction-ordered copies are
+        // wanted, built in the same pass)
+        const bool surely_large = d->n_primitives > 2048;
+        rtdev::BvhBuild bvh = rtdev::build_bvh(d->primitives, d->n_primitives, 4, surely_large);
         int max_leaf = 0;
 #ifdef RT_DEVELOPER_KNOBS
         if (const char *k = getenv("RT_BVH_LEAF")) max_leaf = atoi(k);
@@ -877,6 +882,18 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
         } else if (bvh.nodes.size() * sizeof(rtdev::BvhNode) <= 32 * 1024) { // the nodes live in LDS
             rtdev::BvhBuild three = rtdev::build_bvh(d->primitives, d->n_primitives, 3);
             if (three.nodes.size() * sizeof(rtdev::BvhNode) <= 32 * 1024 && blocks_with(three) == blocks_with(bvh)) bvh = std::move(three);
+        }
+        if (bvh.nodes.size() * sizeof(rtdev::BvhNode) > 32 * 1024) {
+            // the nodes stay in global memory, where a step is two dependent loads and every node not visited counts: the
+            // eight direction-ordered copies (rt_bvh.cpp; 8 x 32 B per node)
+            bool ordered = true;
+#ifdef RT_DEVELOPER_KNOBS
+            if (const char *k = getenv("RT_BVH_ORDERED")) ordered = atoi(k) != 0;
+#endif
+            if (ordered) {
+                if (bvh.ordered.empty()) bvh = rtdev::build_bvh(d->primitives, d->n_primitives, max_leaf > 0 ? max_leaf : 4, true);
+                if ((rc = upload(s->bvh_nodes_ordered, bvh.ordered)) != RT_OK) return rc;
+            }
         }
         if ((rc = upload(s->bvh_nodes, bvh.nodes)) != RT_OK) return rc;
         if ((rc = upload(s->bvh_prim_index, bvh.prim_index)) != RT_OK) return rc;

@@ -60,6 +60,7 @@ namespace {
 struct Node64 { // the builder's own node: f64 box, links as on the device
     double mn[3], mx[3];
     int32_t skip, first, count;
+    int32_t axis = -1; // inner node: the axis its children were sorted along (-1: a chain of full leaves, no order to speak of)
 };
 struct Build64 {
     std::vector<Node64> nodes;
@@ -107,6 +108,7 @@ int emit(Build64 &out, std::vector<Item> &items, int begin, int end, int max_lea
         return me;
     }
     int mid = begin + n / 2;
+    int best_axis_of_split = axis;
     if (axis >= 0) {
         // Surface-area heuristic, full sweep over the three axes: minimise
         // area(L) * |L| + area(R) * |R|.  A plain median split is badly wrong when one
@@ -152,11 +154,13 @@ int emit(Build64 &out, std::vector<Item> &items, int begin, int end, int max_lea
             return a.prim < b.prim;
         });
         mid = best_mid;
+        best_axis_of_split = best_axis;
     } else {
         mid = begin + max_leaf;
     }
     node.first = -1;
     node.count = 0;
+    node.axis = axis >= 0 ? best_axis_of_split : -1;
     out.nodes[(size_t)me] = node;
     emit(out, items, begin, mid, max_leaf);
     emit(out, items, mid, end, max_leaf);
@@ -176,7 +180,7 @@ float round_up(double x) {
 
 } // namespace
 
-BvhBuild build_bvh(const RtPrimitive *prims, int n_prims, int max_leaf) {
+BvhBuild build_bvh(const RtPrimitive *prims, int n_prims, int max_leaf, bool ordered) {
     if (max_leaf < 1) max_leaf = 1;
     if (max_leaf > 7) max_leaf = 7; // BvhNode.first_count keeps the count in three bits
     BvhBuild out;
@@ -226,6 +230,52 @@ BvhBuild build_bvh(const RtPrimitive *prims, int n_prims, int max_leaf) {
     }
     end.skip = (int32_t)out.nodes.size();
     end.first_count = BvhNode::kSentinel;
+    if (ordered) {
+        // DIRECTION-ORDERED COPIES.  The walk visits a node's children in memory order (first child = i + 1), so ONE array
+        // serves rays of one direction well: the child that lies first along the ray shrinks best_t before its sibling
+        // is asked.  Eight arrays, one per sign octant of the ray direction: at a node whose children were split along
+        // axis a, the lower child comes first when the ray travels towards +a, the upper one otherwise.  Same nodes, same
+        // boxes, same leaves (they keep pointing into the one leaf-ordered primitive table): only the order and the skip
+        // links differ.  Array 0 (all components positive) is the array above.
+        const size_t n = tree.nodes.size();
+        std::vector<int32_t> right((size_t)n, -1); // second child of inner node i in the builder's order: skip of its first child
+        for (size_t i = 0; i < n; ++i)
+            if (tree.nodes[i].count == 0) right[i] = tree.nodes[i + 1].skip;
+        out.ordered.assign(8 * (n + 1), BvhNode());
+        for (int oct = 0; oct < 8; ++oct) {
+            BvhNode *arr = out.ordered.data() + (size_t)oct * (n + 1);
+            size_t next = 0;
+            // iterative depth-first emission; `fix` remembers which emitted node's skip link waits for the subtree's end
+            struct Frame { int32_t node; int32_t emitted_at; int stage; };
+            std::vector<Frame> stack;
+            stack.push_back(Frame{0, -1, 0});
+            while (!stack.empty()) {
+                Frame &f = stack.back();
+                const Node64 &nd = tree.nodes[(size_t)f.node];
+                if (f.stage == 0) {
+                    f.emitted_at = (int32_t)next;
+                    arr[next] = out.nodes[(size_t)f.node]; // box and first_count as in array 0
+                    ++next;
+                    if (nd.count > 0) { // leaf
+                        arr[(size_t)f.emitted_at].skip = (int32_t)next;
+                        stack.pop_back();
+                        continue;
+                    }
+                    f.stage = 1;
+                    const bool flip = nd.axis >= 0 && ((oct >> nd.axis) & 1) != 0; // the ray travels towards -axis: upper child first
+                    const int32_t a = f.node + 1, b = right[(size_t)f.node];
+                    const int32_t first = flip ? b : a, second = flip ? a : b;
+                    // (second is pushed first so that `first` is processed next)
+                    stack.push_back(Frame{second, -1, 0});
+                    stack.push_back(Frame{first, -1, 0});
+                } else { // both subtrees are out: everything behind them is where a miss of this node continues
+                    arr[(size_t)f.emitted_at].skip = (int32_t)next;
+                    stack.pop_back();
+                }
+            }
+            arr[n] = out.nodes.back(); // the sentinel
+        }
+    }
     return out;
 }
 

@@ -26,13 +26,14 @@ namespace rtdev {
 
 struct BvhBuild {
     std::vector<BvhNode> nodes;      // compact device form (rt_device_types.h); the LAST entry is the sentinel, not a node of the tree
+    std::vector<BvhNode> ordered;    // optional: eight arrays of nodes.size() entries, one per sign octant of the ray direction (rt_bvh.cpp)
     std::vector<int32_t> prim_index; // leaves refer to ranges of this list
     double root_mn[3], root_mx[3];   // root box, f64, padded like the node boxes
     double center[3];                // the node boxes are relative to this point
 };
 
 // Host-side build over the ABI primitives (wrappers and motion included in the bounds).
-BvhBuild build_bvh(const RtPrimitive *prims, int n_prims, int max_leaf = 4); // max_leaf: primitives per leaf, 1..7
+BvhBuild build_bvh(const RtPrimitive *prims, int n_prims, int max_leaf = 4, bool ordered = false); // max_leaf: primitives per leaf, 1..7; ordered: also the eight direction-ordered arrays
 // True bounds of one primitive incl. RotateY / Translate / motion.
 void primitive_bounds(const RtPrimitive &p, double mn[3], double mx[3]);
 

@@ -212,6 +212,9 @@ struct TraceArgs {
     int32_t total_chunks;         // chunks of the frame (== n_chunks of a single-launch render)
     // BVH (scenes with more primitives than the brute-force loop is good for)
     const BvhNode *bvh_nodes;
+    // trees too large for LDS: eight copies of the node array (n_bvh_nodes + 1 entries each), one per sign octant of the
+    // ray direction, in which the child that lies first along such a ray is the first child (rt_bvh.cpp); NULL otherwise
+    const BvhNode *bvh_nodes_ordered;
     double bvh_root_mn[3], bvh_root_mx[3]; // the root box in f64 (padded like the node boxes)
     double bvh_center[3];                  // origin of the node boxes' coordinates
     const int32_t *bvh_prim_index;

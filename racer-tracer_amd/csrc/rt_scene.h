@@ -80,6 +80,7 @@ struct RtScene {
     // closest hit: linear loop for small scenes, skip-link BVH (rt_bvh.h) above kBvhThreshold primitives
     int use_bvh = 0;
     rtapi::DevBuf<rtdev::BvhNode> bvh_nodes;
+    rtapi::DevBuf<rtdev::BvhNode> bvh_nodes_ordered; // eight direction-ordered copies (trees that do not fit LDS)
     rtapi::DevBuf<int32_t> bvh_prim_index;
     rtapi::DevBuf<rtdev::LeafGeo> leaf_geo; // what a leaf test reads (rt_device_types.h)
     double leaf_time_a = 0.0, leaf_inv_dt = 1.0;

@@ -488,6 +488,10 @@ __device__ __forceinline__ void closest_hit_bvh(const TraceArgs &A, const BvhNod
     const f2 p01 = {sr.ivx, sr.ivy}, p23 = {sr.ivz, sr.nox}, p45 = {sr.noy, sr.noz};
     int i = 0;
     const int n = A.n_bvh_nodes;
+    if (A.bvh_nodes_ordered != nullptr && nodes == A.bvh_nodes) { // the copy of the array ordered for this ray's direction
+        const int oct = (d.x < 0.0 ? 1 : 0) | (d.y < 0.0 ? 2 : 0) | (d.z < 0.0 ? 4 : 0);
+        nodes = A.bvh_nodes_ordered + (size_t)oct * (size_t)(n + 1);
+    }
     while (i < n) {
         int fc = 0;
         // DESCENT: skip / step down until a leaf is entered.  The array ends with a sentinel — an all-space leaf without

@@ -97,7 +97,7 @@ int main(int argc, char **argv) {
     const RtSceneDesc *d = rth_session_scene(session);
     const RtCamera *cam = rth_session_camera(session);
     const int max_leaf = argc > 1 ? atoi(argv[1]) : 4;
-    rtdev::BvhBuild bvh = rtdev::build_bvh(d->primitives, d->n_primitives, max_leaf);
+    rtdev::BvhBuild bvh = rtdev::build_bvh(d->primitives, d->n_primitives, max_leaf, true); // with the eight direction-ordered arrays
     g_bvh = &bvh;
     printf("max %d primitives per leaf: ", max_leaf);
     const int n = (int)bvh.nodes.size() - 1; // the array ends with the walk's sentinel (rt_device_types.h: BvhNode), not a node of the tree
@@ -162,6 +162,32 @@ int main(int argc, char **argv) {
                 i = i + 1;
             } else {
                 i = bvh.nodes[i].skip;
+            }
+        }
+        return steps;
+    };
+    // the same walk over the copy of the node array that is ordered for the ray's direction octant (rt_bvh.cpp; what the
+    // device does for trees that stay in global memory)
+    auto walk_skip_ordered = [&](const Ray &r, Count &c, int &best) {
+        const int oct = (r.d[0] < 0.0 ? 1 : 0) | (r.d[1] < 0.0 ? 2 : 0) | (r.d[2] < 0.0 ? 4 : 0);
+        const rtdev::BvhNode *arr = bvh.ordered.data() + (size_t)oct * (size_t)(n + 1);
+        double bt = INFINITY;
+        best = -1;
+        int i = 0, steps = 0;
+        while (i < n) {
+            ++c.boxes; ++steps;
+            double tn;
+            if (hit_box(arr[i], bvh.center, r, bt, tn)) {
+                const int fc = arr[i].first_count;
+                for (int k = 0; k < (fc & 7); ++k) {
+                    ++c.prims;
+                    const int pi = bvh.prim_index[(fc >> 3) + k];
+                    double t;
+                    if (hit_prim(d->primitives[pi], r, bt, t)) { bt = t; best = pi; }
+                }
+                i = i + 1;
+            } else {
+                i = arr[i].skip;
             }
         }
         return steps;
@@ -363,15 +389,16 @@ int main(int argc, char **argv) {
     // NOTE the ordered walk re-tests a popped node's box implicitly never: a popped far child may have become
     // prunable (best_t shrank); count that variant too
     for (int bounce = 0; bounce < 3; ++bounce) {
-        Count a, b, c2;
-        long wave_a = 0, wave_b = 0, wave_c = 0, mismatches = 0;
+        Count a, b, c2, e;
+        long wave_a = 0, wave_b = 0, wave_c = 0, wave_e = 0, mismatches = 0;
         int max_sp = 0;
         std::vector<Ray> next;
         for (size_t w = 0; w < rays.size(); w += 64) {
-            int ma = 0, mb = 0, mc = 0;
+            int ma = 0, mb = 0, mc = 0, me = 0;
             for (size_t j = w; j < std::min(rays.size(), w + 64); ++j) {
                 int ba, bb;
                 ma = std::max(ma, walk_skip(rays[j], a, ba));
+                { int be; me = std::max(me, walk_skip_ordered(rays[j], e, be)); mismatches += be != ba; }
                 mb = std::max(mb, walk_ordered(rays[j], b, bb, max_sp));
                 mismatches += ba != bb;
                 { int bc; mc = std::max(mc, walk_two(rays[j], c2, bc)); mismatches += bc != ba; }
@@ -404,11 +431,14 @@ int main(int argc, char **argv) {
             wave_a += ma;
             wave_b += mb;
             wave_c += mc;
+            wave_e += me;
         }
         const double nr = (double)rays.size(), nw = std::ceil(nr / 64);
         printf("bounce %d: %zu rays | skip-link: %.1f boxes %.1f prims per ray, %.1f steps per wave | ordered+stack: %.1f boxes %.1f prims per ray, "
-               "%.1f steps per wave (2 boxes each), stack depth %d | skip-link, two per step: %.1f boxes, %.1f steps per wave | closest hits differ: %ld\n",
-               bounce, rays.size(), a.boxes / nr, a.prims / nr, wave_a / nw, b.boxes / nr, b.prims / nr, wave_b / nw, max_sp, c2.boxes / nr, wave_c / nw, mismatches);
+               "%.1f steps per wave (2 boxes each), stack depth %d | skip-link, two per step: %.1f boxes, %.1f steps per wave | "
+               "skip-link over the direction-ordered array: %.1f boxes %.1f prims per ray, %.1f steps per wave | closest hits differ: %ld\n",
+               bounce, rays.size(), a.boxes / nr, a.prims / nr, wave_a / nw, b.boxes / nr, b.prims / nr, wave_b / nw, max_sp, c2.boxes / nr, wave_c / nw,
+               e.boxes / nr, e.prims / nr, wave_e / nw, mismatches);
         { // lockstep model of a wave over this bounce's rays: today's walk against one whose lanes fetch new rays
             std::vector<std::vector<std::pair<int, int>>> traces(rays.size());
             for (size_t j = 0; j < rays.size(); ++j) walk_trace(rays[j], traces[j]);
