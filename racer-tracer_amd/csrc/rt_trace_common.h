@@ -448,6 +448,15 @@ __device__ __forceinline__ bool box_t(const Prim &P, d3 o, d3 d, d3 inv_d, doubl
 // leaf whose box it hits (or has left the tree), THEN the wave tests leaf
 // primitives together.  Mixing the two in one loop body makes a wave pay the
 // primitive tests on almost every step (measured: LABNOTES.md, round-3 section 4.6).
+// The node array a ray of direction d walks when the tree lives in global memory: the copy ordered for d's sign octant
+// (rt_bvh.cpp), or the one array there is.  (Chosen by the CALLER of closest_hit_bvh: selecting inside it would merge the
+// LDS and the global pointer into a flat one and turn the LDS walk's ds_read into flat loads — `random` 39 -> 51 ms.)
+__device__ __forceinline__ const BvhNode *bvh_nodes_for(const TraceArgs &A, d3 d) {
+    if (A.bvh_nodes_ordered == nullptr) return A.bvh_nodes;
+    const int oct = (d.x < 0.0 ? 1 : 0) | (d.y < 0.0 ? 2 : 0) | (d.z < 0.0 ? 4 : 0);
+    return A.bvh_nodes_ordered + (size_t)oct * (size_t)(A.n_bvh_nodes + 1);
+}
+
 struct NoMark { // profile hook of closest_hit_bvh: the regions build passes one that books cycles
     __device__ __forceinline__ void operator()(int) const {}
 };
@@ -488,10 +497,6 @@ __device__ __forceinline__ void closest_hit_bvh(const TraceArgs &A, const BvhNod
     const f2 p01 = {sr.ivx, sr.ivy}, p23 = {sr.ivz, sr.nox}, p45 = {sr.noy, sr.noz};
     int i = 0;
     const int n = A.n_bvh_nodes;
-    if (A.bvh_nodes_ordered != nullptr && nodes == A.bvh_nodes) { // the copy of the array ordered for this ray's direction
-        const int oct = (d.x < 0.0 ? 1 : 0) | (d.y < 0.0 ? 2 : 0) | (d.z < 0.0 ? 4 : 0);
-        nodes = A.bvh_nodes_ordered + (size_t)oct * (size_t)(n + 1);
-    }
     while (i < n) {
         int fc = 0;
         // DESCENT: skip / step down until a leaf is entered.  The array ends with a sentinel — an all-space leaf without

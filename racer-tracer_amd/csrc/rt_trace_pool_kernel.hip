@@ -737,7 +737,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                         if (lds_nodes != nullptr)
                             closest_hit_bvh<PRIMS>(A, lds_nodes, o, d, inv_d, inv_a, ray_time, 0.001, best_t, best, best_aux, walk_stats, walk_mark);
                         else
-                            closest_hit_bvh<PRIMS>(A, A.bvh_nodes, o, d, inv_d, inv_a, ray_time, 0.001, best_t, best, best_aux, walk_stats, walk_mark);
+                            closest_hit_bvh<PRIMS>(A, bvh_nodes_for(A, d), o, d, inv_d, inv_a, ray_time, 0.001, best_t, best, best_aux, walk_stats, walk_mark);
 #ifdef RT_PROFILE_REGIONS
                         atomicAdd(&rt_t_[37], (unsigned long long)walk[0]); // per-lane totals (LDS atomics)
                         atomicAdd(&rt_t_[38], (unsigned long long)walk[1]);

@@ -74,3 +74,19 @@ def test_no_scratch_in_the_plain_variants(pool_kernel_asm):
         vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(0)).group(1))
         scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(0)).group(1))
         assert vgprs <= max_vgprs and scratch == 0, (variant, vgprs, scratch)
+
+
+def test_bvh_walk_reads_its_nodes_from_lds_not_through_flat_addresses(pool_kernel_asm):
+    """The BVH variants walk the node array in LDS (two ds_read_b128 per step) or, for large trees, in global memory (two
+    global_load_dwordx4) — two instantiations of one routine.  A pointer that may be either (a select between the two
+    inside the routine) turns every node read into a flat load: `random` went from 39 to 51 ms that way in round 4.
+    Both forms of the step must be there, and no 128-bit flat load (a node read) anywhere in the kernel."""
+    text = "\n".join(pool_kernel_asm)
+    for variant in ("Li2ELb0ELb0ELb1E", "Li2ELb1ELb1ELb1E"):
+        start = text.index("\n_ZN10rtdev_fast16k_trace_pool_f64I" + variant)
+        body = text[start:text.index(".Lfunc_end", start)]
+        assert "flat_load_dwordx4" not in body, variant
+        steps = [m.start() for m in re.finditer(r"v_pk_fma_f32", body)]
+        assert len(steps) == 6, (variant, len(steps))                     # three per step, two instantiations
+        assert re.search(r"ds_read_b128[^\n]*\n(?:[^\n]*\n){0,12}?[^\n]*v_pk_fma_f32", body), variant
+        assert re.search(r"global_load_dwordx4[^\n]*\n(?:[^\n]*\n){0,12}?[^\n]*v_pk_fma_f32", body), variant
