@@ -12,7 +12,10 @@ kernel does not use:
 
     s_mov_b64 s[100:101], exec ; s_mov_b32 exec_lo, <bit> ; s_mov_b32 exec_hi, <bit> ; v_add_u32 vC, 1, vC ; s_mov_b64 exec, s[100:101]
 
-(no SCC, VCC or M0 is touched; s100/s101 lie above the 100 SGPRs the kernels use).  The counters are zeroed at kernel
+(no SCC, VCC or M0 is touched; s100/s101 lie above the 100 SGPRs the kernels use).  A second set of counters takes the
+number of ENABLED LANES of every visit (popcount of the exec mask, formed without the scalar ALU: v_mbcnt + the lane's own
+bit in lane 63, handed to the block's counter lane through ds_bpermute): visits x instructions are what the wave issues,
+lanes / visits is how much of each issue was useful.  The counters are zeroed at kernel
 entry and added to the device array `rt_bb_counts` (64-bit atomics) before every s_endpgm.  The code the compiler
 generated is otherwise untouched, so   count(block) x instructions(block)   summed over the blocks is what the
 product kernel issues, instruction by instruction: tools/bb_profile.py prints it by opcode and checks the class totals
@@ -36,7 +39,8 @@ LABEL = re.compile(r"^(\.LBB\d+_\d+):")
 FUNC = re.compile(r"^(_Z\w+):")
 TERMINATORS = ("s_branch", "s_cbranch_", "s_endpgm", "s_setpc_b64")
 COUNTS_SYMBOL = "rt_bb_counts"
-MAX_BLOCKS = 8192
+MAX_BLOCKS = 4096   # rt_bb_counts holds RT_BB_MAX = 8192 entries: visits at [id], enabled lanes at [LANES_AT + id]
+LANES_AT = 4096
 
 
 def functions(lines):
@@ -147,10 +151,14 @@ def main():
             if ins[0].startswith(TERMINATORS):
                 cur = None
     if len(blocks) > MAX_BLOCKS:
-        sys.exit("%d blocks: raise MAX_BLOCKS (and RT_BB_MAX in rt_trace_pool_kernel.hip)" % len(blocks))
+        sys.exit("%d blocks: raise MAX_BLOCKS / LANES_AT (and RT_BB_MAX in rt_trace_pool_kernel.hip)" % len(blocks))
     n_counters = (len(blocks) + 63) // 64
-    c0 = n_vgpr                       # counter VGPRs c0 .. c0 + n_counters - 1
-    t_off = c0 + n_counters           # scratch: byte offset of this lane's counter
+    c0 = n_vgpr                       # visit counters c0 .. c0 + n_counters - 1
+    l0 = c0 + n_counters              # lane counters l0 .. l0 + n_counters - 1 (sum of enabled lanes over the visits)
+    t_cnt = l0 + n_counters           # scratch: popcount of exec (valid in lane 63), then broadcast
+    t_bit = t_cnt + 1                 # scratch: the lane's own exec bit
+    t_adr = t_cnt + 2                 # constant 252: byte address of lane 63 for ds_bpermute (set at kernel entry)
+    t_off = t_cnt + 3                 # scratch: byte offset of this lane's counter (flush)
     t_pair = (t_off + 2) & ~1         # scratch pair (even-aligned) for the 64-bit atomic's data
     new_vgpr = (t_pair + 2 + 7) & ~7
     if new_vgpr > 512:
@@ -159,10 +167,19 @@ def main():
     def bump(bid):
         lane = bid % 64
         lo, hi = (1 << lane) & 0xffffffff, (1 << lane) >> 32
-        v = c0 + bid // 64
+        v, vl = c0 + bid // 64, l0 + bid // 64
         return ["\ts_mov_b64 s[100:101], exec\t; bb %d" % bid,
+                "\ts_mov_b64 exec, -1",
+                "\tv_mbcnt_lo_u32_b32 v%d, s100, 0" % t_cnt,
+                "\tv_mbcnt_hi_u32_b32 v%d, s101, v%d" % (t_cnt, t_cnt),          # set bits of the saved mask below this lane
+                "\tv_cndmask_b32_e64 v%d, 0, 1, s[100:101]" % t_bit,            # this lane's own bit
+                "\tv_add_u32_e32 v%d, v%d, v%d" % (t_cnt, t_cnt, t_bit),          # lane 63: popcount(exec)
+                "\tds_bpermute_b32 v%d, v%d, v%d" % (t_cnt, t_adr, t_cnt),        # ... to every lane
+                "\ts_waitcnt lgkmcnt(0)",
                 "\ts_mov_b32 exec_lo, 0x%x" % lo, "\ts_mov_b32 exec_hi, 0x%x" % hi,
-                "\tv_add_u32_e32 v%d, 1, v%d" % (v, v), "\ts_mov_b64 exec, s[100:101]"]
+                "\tv_add_u32_e32 v%d, 1, v%d" % (v, v),
+                "\tv_add_u32_e32 v%d, v%d, v%d" % (vl, t_cnt, vl),
+                "\ts_mov_b64 exec, s[100:101]"]
 
     flush = ["\ts_mov_b64 exec, -1\t; bb flush",
              "\ts_getpc_b64 s[100:101]",
@@ -172,17 +189,20 @@ def main():
              "\tv_mbcnt_hi_u32_b32 v%d, -1, v%d" % (t_off, t_off),
              "\tv_lshlrev_b32_e32 v%d, 3, v%d" % (t_off, t_off),
              "\tv_mov_b32_e32 v%d, 0" % (t_pair + 1)]
-    for j in range(n_counters):
-        flush += ["\tv_mov_b32_e32 v%d, v%d" % (t_pair, c0 + j),
-                  "\tglobal_atomic_add_x2 v%d, v[%d:%d], s[100:101]" % (t_off, t_pair, t_pair + 1),
-                  "\tv_add_u32_e32 v%d, 0x200, v%d" % (t_off, t_off)]
+    # lane l of counter register j holds block 64 j + l: entry (base + 64 j + l) of rt_bb_counts, 512 bytes per register
+    for base, first in ((0, c0), (LANES_AT, l0)):
+        for j in range(n_counters):
+            flush += ["\tv_mov_b32_e32 v%d, v%d" % (t_pair, first + j),
+                      "\tv_add_u32_e32 v%d, 0x%x, v%d" % (t_cnt, base * 8 + j * 512, t_off),
+                      "\tglobal_atomic_add_x2 v%d, v[%d:%d], s[100:101]" % (t_cnt, t_pair, t_pair + 1)]
     flush += ["\ts_waitcnt vmcnt(0)"]
 
     out = []
     first_kernel_inst = next(i for i in range(kernel[1], kernel[2]) if instruction_of(lines[i]))
     for i, l in enumerate(lines):
         if i == first_kernel_inst:
-            out += ["\tv_mov_b32_e32 v%d, 0\t; bb counters" % (c0 + j) for j in range(n_counters)]
+            out += ["\tv_mov_b32_e32 v%d, 0\t; bb counters" % (c0 + j) for j in range(2 * n_counters)]
+            out += ["\tv_mov_b32_e32 v%d, 0xfc\t; lane 63 for ds_bpermute" % t_adr]
         if i in insert_before:
             out += bump(insert_before[i])
         if kernel[1] <= i < kernel[2] and instruction_of(l) and instruction_of(l)[0] == "s_endpgm":
@@ -200,7 +220,7 @@ def main():
     if meta:
         text = text[:meta.start(2)] + str(new_vgpr) + text[meta.end(2):]
     open(out_s, "w").write(text)
-    json.dump({"kernel": kernel[0], "variant": variant, "n_blocks": len(blocks), "counter_vgprs": [c0, c0 + n_counters - 1],
+    json.dump({"kernel": kernel[0], "variant": variant, "n_blocks": len(blocks), "counter_vgprs": [c0, c0 + n_counters - 1], "lane_counters_at": LANES_AT,
                "vgprs_before": n_vgpr, "vgprs_after": new_vgpr, "blocks": blocks}, open(out_json, "w"))
     n_inst = sum(len(b["insts"]) for b in blocks)
     with_line = sum(1 for b in blocks for i in b["insts"] if i[2])

@@ -161,10 +161,13 @@ def main():
     torch.cuda.synchronize()
     st = scene.last_stats()
     n = blocks["n_blocks"]
-    raw = (C.c_ulonglong * n)()
-    if lib.rtdev_bb_counts(raw, n, 0) != n:
+    lanes_at = blocks.get("lane_counters_at")  # builds with lane counters: enabled lanes of every visit, summed, at [lanes_at + id]
+    n_read = n if lanes_at is None else lanes_at + n
+    raw = (C.c_ulonglong * n_read)()
+    if lib.rtdev_bb_counts(raw, n_read, 0) != n_read:
         sys.exit("rtdev_bb_counts failed")
-    counts = list(raw)
+    counts = list(raw[:n])
+    lanes = list(raw[lanes_at:lanes_at + n]) if lanes_at is not None else None
     if not any(counts):
         sys.exit("all counters are zero: variant %s did not run for workload %s" % (variant, workload))
     # the frame must be the product's frame (the counters must not have disturbed anything)
@@ -192,11 +195,15 @@ def main():
     cyc_line = collections.Counter()
     cyc_func = collections.Counter()
     cyc_op = collections.Counter()
+    lanes_func = collections.Counter()   # enabled lanes summed over the vector instructions issued (SQ_THREAD_CYCLES-like, in lane-issues)
+    lanes_line = collections.Counter()
+    lanes_total = 0
     cache, fcache = {}, {}
     for b in blocks["blocks"]:
         c = counts[b["id"]]
         if c == 0:
             continue
+        lv = lanes[b["id"]] if lanes else 0  # every instruction of a block runs under the mask the block was entered with
         for op, _operands, where in b["insts"]:
             u = unit_of(op)
             by_unit[u] += c
@@ -209,6 +216,9 @@ def main():
                 cyc_line[where] += cy
                 cyc_func[function_of(cache, fcache, where)] += cy
                 cyc_op[short(op)] += cy
+                lanes_func[function_of(cache, fcache, where)] += lv
+                lanes_line[where] += lv
+                lanes_total += lv
             if u != "other":
                 by_line[where] += c
                 by_func[function_of(cache, fcache, where)] += c
@@ -278,19 +288,37 @@ def main():
     for f, c in by_func_valu.most_common(30):
         emit("  %-44s %14.6g  %6.2f %%  %8.4f" % (f, c, 100.0 * c / total_valu, c / segs))
     emit()
+    if lanes:
+        # DIVERGENCE: enabled lanes of every block visit.  An instruction issued with L of 64 lanes enabled wastes (64 - L) / 64
+        # of its issue; "idle share" = the function's / line's part of ALL idle lane-issues of the launch.
+        idle_total = 64.0 * total_valu - lanes_total
+        emit("lanes enabled per vector instruction: %.2f of 64 over the launch (%.1f %% of the lane-issues idle)"
+             % (lanes_total / total_valu, 100.0 * idle_total / (64.0 * total_valu)))
+        if pmc and "SQ_THREAD_CYCLES_VALU" in pmc[1] and "SQ_ACTIVE_INST_VALU" in pmc[1]:
+            emit("  (PMC summary, cycle-weighted: SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU = %.2f)"
+                 % (pmc[1]["SQ_THREAD_CYCLES_VALU"]["mean"] / pmc[1]["SQ_ACTIVE_INST_VALU"]["mean"]))
+        emit("  by source function: vector instructions, share, lanes per instruction, share of the idle lane-issues")
+        for f, c in by_func_valu.most_common(30):
+            emit("  %-44s %14.6g  %6.2f %%  %6.2f  %6.2f %%" % (f, c, 100.0 * c / total_valu, lanes_func[f] / c, 100.0 * (64.0 * c - lanes_func[f]) / idle_total))
+        emit("  by source line, top 40 by idle lane-issues: share of the instructions, lanes per instruction, share of the idle lane-issues")
+        for where, idle in sorted(((w, 64.0 * by_line_valu[w] - lanes_line[w]) for w in by_line_valu), key=lambda kv: -kv[1])[:40]:
+            c = by_line_valu[where]
+            emit("  %-26s %6.2f %%  %6.2f  %6.2f %%   %s" % (where or "(no line)", 100.0 * c / total_valu, lanes_line[where] / c, 100.0 * idle / idle_total, source_text(cache, where)))
+        emit()
     emit("vector instructions by source line, top 60 (share, per segment)")
     for where, c in by_line_valu.most_common(60):
         emit("  %-26s %6.2f %%  %7.4f   %s" % (where or "(no line)", 100.0 * c / total_valu, c / segs, source_text(cache, where)))
     emit()
-    emit("blocks by visits, top 40: id, visits, visits per segment, instructions (v/s), label, first source line")
+    emit("blocks by visits, top 40: id, visits, visits per segment, instructions (v/s), lanes per visit, label, first source line")
     order = sorted(blocks["blocks"], key=lambda b: -counts[b["id"]] * len(b["insts"]))[:40]
     for b in order:
         nv = sum(1 for i in b["insts"] if i[0].startswith("v_"))
         ns = sum(1 for i in b["insts"] if i[0].startswith("s_"))
         first = next((i[2] for i in b["insts"] if i[2]), "")
-        emit("  %4d %14.6g %8.4f  %3d/%3d  %-12s %s" % (b["id"], counts[b["id"]], counts[b["id"]] / segs, nv, ns, b["label"][:12], first))
+        lpv = "%5.1f" % (lanes[b["id"]] / counts[b["id"]]) if lanes and counts[b["id"]] else "    -"
+        emit("  %4d %14.6g %8.4f  %3d/%3d  %s  %-12s %s" % (b["id"], counts[b["id"]], counts[b["id"]] / segs, nv, ns, lpv, b["label"][:12], first))
     if out:  # the raw visit counts, for tools/bb_query.py
-        json.dump({"workload": name, "variant": variant, "segments": segs, "samples": float(st.samples), "counts": counts},
+        json.dump({"workload": name, "variant": variant, "segments": segs, "samples": float(st.samples), "counts": counts, "lanes": lanes},
                   open(os.path.splitext(sys.argv[3])[0] + "_counts.json", "w"))
     scene.close()
     sc2.close()
