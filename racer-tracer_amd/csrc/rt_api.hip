@@ -7,6 +7,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
 #include <cmath>
 #include <atomic>
 #include <mutex>
@@ -242,6 +243,7 @@ void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtd
     }
     a.cam.lens_radius = c->lens_radius;
     a.lens_lds = c->lens_radius != 0.0;
+    a.time_lds = s->has_moving;
     a.cam.time_a = c->time_a;
     a.cam.time_b = c->time_b;
     a.bg = s->bg;
@@ -263,6 +265,19 @@ void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtd
     for (int g = 0; g < 3; ++g) a.rect_end[g] = s->rect_end[g];
     a.sphere_end = s->sphere_end;
     a.box_end = s->box_end;
+    // Fixed-point sums (rt_device_types.h: sum_scale): a sample's radiance is at most radiance_bound < 2^e, so
+    // T * 2^(52 - e) < 2^52 — what the kernel's conversion can hold — and 2048 of them, the samples of the longest chunk
+    // (or the scale halves), stay below 2^63.
+    if (!s->exact && !s->use_v1 && s->radiance_bound > 0.0) {
+        int e = 0;
+        (void)frexp(s->radiance_bound, &e); // radiance_bound < 2^e
+        const std::vector<int> plan = chunk_plan(p->samples);
+        int longest = 1;
+        for (size_t k = 0; k + 1 < plan.size(); ++k) longest = std::max(longest, plan[k + 1] - plan[k]);
+        for (; longest > 2048; longest = (longest + 1) / 2) ++e;
+        a.sum_scale = ldexp(1.0, 52 - e);
+        a.sum_unscale = ldexp(1.0, e - 52);
+    }
 #ifdef RT_DEVELOPER_KNOBS // throw-away kernel knobs of the developer build (tools/perf_ab.sh)
     for (int k = 0; k < 4; ++k) {
         char name[16];
@@ -783,6 +798,60 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
         }
     }
     for (rtdev::Prim &q : prims) q.mat = materials[(size_t)q.material]; // the only device copy of a material
+    // What a finished sample can be at most (RtScene.radiance_bound): the product of its path's attenuations times what the
+    // path ran into.  Attenuations are texture values (lambertian.rs:36, metal.rs:40) or 1 (dialectric.rs:26) — a
+    // SolidColor's colour, a Noise colour times 0.5 (1 + sin) <= the colour, an image texel <= 1 — so with every such colour
+    // in [0, 1] the bound is the largest of 1 (renderer.rs:48-55: white at depth 0), the emitted colours
+    // (diffuse_light.rs:33-35) and the background's.  A colour outside [0, 1] on a scattering material, or anything
+    // negative or not finite, leaves the scene without a bound (0): the pooled kernel then keeps f64 sums.
+    {
+        bool bounded = true;
+        double bound = 1.0;
+        auto colours_of = [&](int ti, double &hi, double &lo) { // over the texture and, for a Checkered, its two sides
+            auto one = [&](const RtTexture &t) {
+                if (t.kind == RT_TEX_IMAGE) {
+                    hi = std::max(hi, 1.0);
+                    lo = std::min(lo, 0.0);
+                    return;
+                }
+                if (t.kind == RT_TEX_CHECKERED) return;
+                for (int k = 0; k < 3; ++k) {
+                    if (!std::isfinite(t.color[k])) bounded = false;
+                    hi = std::max(hi, t.color[k]);
+                    lo = std::min(lo, t.color[k]);
+                }
+            };
+            const RtTexture &t = d->textures[ti];
+            one(t);
+            if (t.kind == RT_TEX_CHECKERED) {
+                one(d->textures[t.tex_even]);
+                one(d->textures[t.tex_odd]);
+                // (a Checkered inside a Checkered is not evaluated further by the kernels: texture_value_deferred returns its colour field)
+                for (int side : {t.tex_even, t.tex_odd})
+                    if (d->textures[side].kind == RT_TEX_CHECKERED)
+                        for (int k = 0; k < 3; ++k) {
+                            if (!std::isfinite(d->textures[side].color[k])) bounded = false;
+                            hi = std::max(hi, d->textures[side].color[k]);
+                            lo = std::min(lo, d->textures[side].color[k]);
+                        }
+            }
+        };
+        for (int i = 0; i < d->n_materials; ++i) {
+            const RtMaterial &m = d->materials[i];
+            if (m.kind == RT_MAT_DIELECTRIC) continue;
+            double hi = 0.0, lo = 0.0;
+            colours_of(m.texture, hi, lo);
+            if (lo < 0.0) bounded = false;
+            if (m.kind == RT_MAT_DIFFUSE_LIGHT) bound = std::max(bound, hi);
+            else if (hi > 1.0) bounded = false;
+        }
+        for (int k = 0; k < 3; ++k)
+            for (double c : {d->background.top[k], d->background.bottom[k]}) {
+                if (!std::isfinite(c) || c < 0.0) bounded = false;
+                bound = std::max(bound, c);
+            }
+        s->radiance_bound = bounded && std::isfinite(bound) && bound < 0x1p40 ? bound : 0.0;
+    }
     std::vector<rtdev::Image> images((size_t)d->n_images);
     s->image_pixels.assign((size_t)d->n_images, nullptr);
     for (int i = 0; i < d->n_images; ++i) {
@@ -826,6 +895,8 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
         if (q.flags || q.kind != RT_PRIM_SPHERE) only_spheres = false;
     }
     s->prims_class = only_rects ? 0 : (only_spheres ? 1 : 2);
+    for (const rtdev::Prim &q : prims)
+        if (q.kind == RT_PRIM_MOVING_SPHERE) s->has_moving = 1;
     for (const rtdev::Material &q : materials) {
         if (q.kind == RT_MAT_METAL || q.kind == RT_MAT_DIELECTRIC) s->specular = 1;
         if (q.kind != RT_MAT_DIELECTRIC && q.tex_kind != RT_TEX_SOLID_COLOR) s->textured = 1;
@@ -836,6 +907,10 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
     const int kBvhThreshold = 48;
     s->use_bvh = d->n_primitives > kBvhThreshold;
     if (opt.closest_hit != RT_HIT_AUTO) s->use_bvh = opt.closest_hit == RT_HIT_BVH && d->n_primitives > 0;
+    // The RT_ARITH_FAST copies of the pooled variants that keep two items in flight (any primitive kind, BVH:
+    // rt_trace_pool_kernel.hip, OVERLAP) have fixed-point sums only: a scene without a radiance bound is rendered by their
+    // RT_ARITH_REFERENCE copies (f64 sums, one item per wave at a time, the reference's own divisions: ~25 % slower).
+    if (s->radiance_bound == 0.0 && opt.kernel == RT_KERNEL_POOL && (s->use_bvh || s->prims_class == 2)) s->exact = true;
     // the linear-loop variants keep the whole primitive table in LDS
     if (!s->use_bvh && (size_t)d->n_primitives * sizeof(rtdev::Prim) > 120 * 1024)
         return fail(RT_ERR_UNSUPPORTED, "RT_HIT_LINEAR: the primitive table does not fit in LDS");
@@ -864,7 +939,8 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
         // global memory, the node from LDS; `random`: 40 % of the walk for 5.8 tests against 26.5 nodes per
         // segment), so leaves of three beat leaves of four (66.1 -> 62.1 ms) — as long as the larger node array
         // does not cost the variant a block per CU (leaves of two: 70.6 ms with three blocks instead of four).
-        const size_t lds_other = s->textured && d->n_perlins > 0 && s->perlin_identity ? sizeof(double) * 256 * 3 : 0;
+        const size_t lds_other = (s->textured && d->n_perlins > 0 && s->perlin_identity ? sizeof(double) * 256 * 3 : 0) +
+                                 (s->has_moving ? rtdev::pool_time_lds_bytes(true) : 0);
         auto blocks_with = [&](const rtdev::BvhBuild &b) {
             const size_t bytes = b.nodes.size() * sizeof(rtdev::BvhNode);
             return (s->exact ? rtdev_pool_blocks_per_cu_exact : rtdev_pool_blocks_per_cu)(s->prims_class, s->textured, s->specular, 1, (bytes <= 32 * 1024 ? bytes : 0) + lds_other);
@@ -958,7 +1034,8 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
     // dynamic LDS of the variant: the BVH node array, or the primitive table of the linear-loop variants
     const size_t dyn_lds = (s->use_bvh ? (s->bvh_nodes_in_lds ? (size_t)(s->n_bvh_nodes + 1) * sizeof(rtdev::BvhNode) : 0)
                                        : (size_t)s->n_prims * sizeof(rtdev::Prim) + (s->textured ? (size_t)s->n_textures * sizeof(rtdev::Texture) : 0)) +
-                           (s->textured && s->n_perlins > 0 && s->perlin_identity ? sizeof(double) * 256 * 3 : 0);
+                           (s->textured && s->n_perlins > 0 && s->perlin_identity ? sizeof(double) * 256 * 3 : 0) +
+                           (s->has_moving ? rtdev::pool_time_lds_bytes(s->use_bvh != 0) : 0);
     s->pool_blocks_per_cu = (s->exact ? rtdev_pool_blocks_per_cu_exact : rtdev_pool_blocks_per_cu)(s->prims_class, s->textured, s->specular, s->use_bvh, dyn_lds);
     s->pool_blocks_per_cu_lens = (s->exact ? rtdev_pool_blocks_per_cu_exact : rtdev_pool_blocks_per_cu)(s->prims_class, s->textured, s->specular, s->use_bvh,
                                                           dyn_lds + rtdev::pool_lens_lds_bytes(s->use_bvh != 0));

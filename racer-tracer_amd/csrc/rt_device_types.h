@@ -103,6 +103,8 @@ static_assert(sizeof(LeafGeo) == 64, "LeafGeo must be 64 bytes");
 // dynamic LDS of the pooled kernel's lens-disk samples per block: 4 waves x NBUF batches x 64 entries x (x, y);
 // NBUF = 1 in the BVH variants, 2 elsewhere (rt_trace_pool_kernel.hip: WaveLds)
 inline size_t pool_lens_lds_bytes(bool bvh) { return (size_t)4 * (bvh ? 1 : 2) * 64 * 2 * sizeof(double); }
+// ... and of the batches' ray times, when the scene has a MovingSphere: 4 waves x NBUF batches x 64 entries
+inline size_t pool_time_lds_bytes(bool bvh) { return (size_t)4 * (bvh ? 1 : 2) * 64 * sizeof(double); }
 
 struct Camera { // what get_ray reads (camera.rs:326-337)
     double origin[3], ulc[3], right[3], up[3], horizontal[3], vertical[3];
@@ -230,6 +232,18 @@ struct TraceArgs {
     int32_t sphere_end;
     int32_t box_end;
     int32_t lens_lds;      // the camera has an aperture: the lens-disk samples of the batches sit at the end of dynamic LDS
+    // FIXED-POINT SUMS (the pooled variants that keep two items in flight: rt_trace_pool_kernel.hip, OVERLAP).  sum_scale =
+    // 2^k: a finished sample's radiance T is added to its pixel's sum as the INTEGER round(T * sum_scale) (< 2^52: the host
+    // derives k from a bound on the scene's radiance — every attenuation <= 1, emission and background <= E — and on the
+    // samples of a chunk, so the 64-bit sums cannot overflow), and the item's sum is that integer, rounded once, times
+    // sum_unscale = 2^-k.  Integer sums do not depend on the order of their terms, which is what lets a wave start its next
+    // item while the last paths of the previous one are still in flight without the frame depending on scheduling.  The
+    // price is an ABSOLUTE quantum of E 2^-52 per sample where a double has a relative one: a pixel whose radiance is of
+    // that order — black, for every purpose — comes out up to sqrt(E 2^-53) (4e-8 for E = 16) from the f64 sum's value.
+    // The other variants, and every RT_ARITH_REFERENCE kernel, add doubles in the order the samples finish, one item at a time.
+    double sum_scale, sum_unscale;
+    int32_t time_lds;  // the scene has a MovingSphere: the ray times of the batches sit behind the lens samples in dynamic LDS
+    int32_t _pad_sum;
     int32_t dbg[4];        // developer knobs (env RT_DBG0..3), 0 in production
 };
 

@@ -75,7 +75,11 @@ struct RtScene {
     int sphere_end = 0;          // ... and of the plain-sphere group behind them
     int box_end = 0;             // ... and of the boxes (wrapped or not) behind those
     int textured = 0; // some material's texture is not a plain SolidColor
+    // upper bound of a finished sample's radiance (every attenuation in [0, 1]; emission, background and the depth-0 white
+    // below it), or 0 when the scene has none (rt_api.hip: scene_create): what sizes the pooled kernel's fixed-point sums
+    double radiance_bound = 0.0;
     int specular = 0; // some material is Metal or Dielectric
+    int has_moving = 0; // some primitive is a MovingSphere (the only reader of a ray's time)
 
     // closest hit: linear loop for small scenes, skip-link BVH (rt_bvh.h) above kBvhThreshold primitives
     int use_bvh = 0;

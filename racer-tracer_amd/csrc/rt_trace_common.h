@@ -56,6 +56,19 @@ __device__ __forceinline__ const RT_CONSTANT TraceArgs *kernargs_here() {
     return p;
 }
 
+// Wave votes and lane shuffles without the library's wrappers.  HIP's ballot(int) turns its predicate into an integer and
+// back (v_cndmask_b32 0 / 1, v_cmp_ne_u32: two vector instructions in front of every ballot — a dozen ballots an
+// iteration); the builtin takes the comparison's own lane mask.  __shfl adds the lane's row base for widths below 64
+// (v_and_or_b32), which a wave-wide shuffle does not need.
+__device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ int shfl_i(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+__device__ __forceinline__ double shfl_d(double v, int src_lane) {
+    const long long bits = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)bits);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)((unsigned long long)bits >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // ------------------------------------------------------------------ vec3
 struct d3 {
     double x, y, z;

@@ -55,6 +55,10 @@
 //    direction (the incoming one is dead), and a finished path's contribution is formed in the throughput.  Every
 //    value kept beside those cost registers and, where the material arms meet, a copy per arm.
 //
+// 9. TWO ITEMS IN FLIGHT (the variants with any primitive kind or a BVH).  The lanes an item's last paths no longer need
+//    start the NEXT item's paths; per-pixel sums are 64-bit fixed-point integers, so the order in which samples arrive —
+//    which now depends on what else the wave traces — cannot change a bit of the frame (SUMS AND OVERLAPPED ITEMS below).
+//
 // The launch is VALU-throughput bound (DESIGN.md 4.2 / 6 and LABNOTES.md have the counters, the per-region
 // cycle profile of the -DRT_PROFILE_REGIONS build, and the variants that were measured and
 // dropped).
@@ -97,7 +101,7 @@ namespace RT_KNS {
 // usable inside divergent code: the first ACTIVE lane books the time since the previous marker
 #define RT_REGION(k)                                                            \
     do {                                                                        \
-        const unsigned long long act_ = __ballot(1);                            \
+        const unsigned long long act_ = ballot(1);                            \
         if (lane_rank(act_) == 0) {                                             \
             const unsigned long long now_ = __builtin_readcyclecounter();       \
             rt_t_[k] += now_ - rt_t_[16];                                       \
@@ -154,9 +158,20 @@ struct alignas(16) Req4 { // one 128-bit LDS access
 // an iteration end before its sampler rounds begin, and both finish with what they posted), so they share
 // their LDS: the textured variants — the BVH ones above all, whose node array already fills LDS to
 // three blocks per CU — cost no more LDS than the plain ones.
-union SamplerScratch {
-    Req4 req[64];
+// (A round of the samplers that has more than 32 requests open gives every lane its own candidate and touches no slot, so 32
+// slots are all they use; variants without textures have no Noise lookups to make room for.)
+template <bool TEXTURED> union SamplerScratch {
+    Req4 req[32];
     NoiseSlots noise;
+};
+template <> union SamplerScratch<false> {
+    Req4 req[32];
+};
+
+// What the END of an item needs of it (finish_item), parked while the item's last paths are in flight and the wave already
+// hands out the next item's.
+struct alignas(16) ItemInfo {
+    int chunk, tx, ty, tile_py0, region, reg_tiles, rows_aligned, _pad;
 };
 
 // Per-wave scratch in LDS.  HAS_TIME: the scene has MovingSpheres (PRIMS_ANY variants).
@@ -164,17 +179,26 @@ union SamplerScratch {
 // The lens-disk samples of a batch (16 B per entry) are NOT in here: only a camera with an aperture draws them, and
 // without their 8 KB per block the plain variants fit six blocks per CU instead of five (cornell 85.2 -> 82.1 ms).
 // They live behind everything else in DYNAMIC LDS, which the launch sizes by the camera (TraceArgs.lens_lds).
-template <bool HAS_TIME, int NBUF> struct WaveLds {
-    // per pixel of the item's tile: upper_left_corner + u * horizontal with the pixel's ONE
-    // horizontal jitter u = (px + ju) / (W - 1) (cpu.rs:35-36, camera.rs:331)
-    double base[64][3];
-    double sum[64][3];  // per-pixel radiance sums of the current item
-    SamplerScratch scratch; // cooperative sampler requests / Noise lookups
-    int pix_of[64];     // pool slot -> lane-order pixel index, for tiles cut by the image edge
+// OVERLAP: the variant keeps two items in flight (see SUMS AND OVERLAPPED ITEMS in the kernel): two sets of sums, and — to pay
+// for them — the per-pixel `base` vector is replaced by the jitter it is made of.
+template <bool TEXTURED, int NBUF, bool OVERLAP> struct WaveLds {
+    // per pixel of the CURRENT item's tile (the one entries are handed out of): upper_left_corner + u * horizontal with the
+    // pixel's ONE horizontal jitter u = (px + ju) / (W - 1) (cpu.rs:35-36, camera.rs:331) — or, OVERLAP, just u: the
+    // hand-out then forms the vector (three fma and a read of `ulc` per iteration for 1 KB)
+    double base[OVERLAP ? 1 : 64][3];
+    double u[OVERLAP ? 64 : 1];
+    // per-pixel radiance sums: doubles — or, OVERLAP, 64-bit fixed-point integers (TraceArgs.sum_scale) of the (up to) two
+    // items in flight: slot s, pixel p at [s * 64 + p]
+    double sum[OVERLAP ? 128 : 64][3];
+    SamplerScratch<TEXTURED> scratch; // cooperative sampler requests / Noise lookups
+    uint8_t pix_of[64]; // pool slot -> lane-order pixel index, for tiles cut by the image edge (current item)
     // Camera samples of the pool entries, drawn 64 entries at a time by the WHOLE wave
     // (prepare_batch below): entry w sits in slot w & 63 of buffer (w >> 6) & (NBUF - 1).
     double v[NBUF][64];        // (py + jv) / (H - 1)                      cpu.rs:39-40
-    double time[HAS_TIME ? NBUF : 1][HAS_TIME ? 64 : 1]; // ray time      camera.rs:335
+    ItemInfo info[2];
+    // camera.upper_left_corner, for the hand-out: v_fma_f64 reads ONE scalar operand, so of upper_left_corner + u * horizontal
+    // one vector has to come from vector registers — copied there with six v_mov_b32 per iteration, or read from here
+    double ulc[3];
 };
 
 // vec3.rs:424-430 for every lane with `need`, evaluated by the whole wave.
@@ -186,7 +210,7 @@ __device__ __forceinline__ bool coop_random_in_unit_sphere(bool need, uint32_t p
                                                            uint32_t &base, uint32_t k0, uint32_t k1, int lane,
                                                            Req4 *req, int max_rounds, d3 &result) {
     bool have = false;
-    uint64_t pending = __ballot(need);
+    uint64_t pending = ballot(need);
     for (int round = 0; round < max_rounds && pending != 0; ++round) {
         const int n = __popcll(pending);
         // a round costs the whole wave ~70 instructions; past the first it only runs while enough requests are
@@ -207,7 +231,7 @@ __device__ __forceinline__ bool coop_random_in_unit_sphere(bool need, uint32_t p
                     base += 1u;
                 }
             }
-            pending = __ballot(need);
+            pending = ballot(need);
             continue;
         }
         const int rank = lane_rank(pending);
@@ -218,14 +242,14 @@ __device__ __forceinline__ bool coop_random_in_unit_sphere(bool need, uint32_t p
         const Req4 r = req[serving ? j : 0];
         const uint32_t i = r.w + (uint32_t)c;  // candidate index = its block (rt_rng.h)
         const d3 p = sphere_candidate(philox4x32(r.x, r.y, (r.z << 8) | RT_RNG_SCATTER, i, k0, k1));
-        const uint64_t accepted = __ballot(serving && len2(p) < 1.0);
+        const uint64_t accepted = ballot(serving && len2(p) < 1.0);
         // first accepted candidate of my own request, in stream order
         const int first = need ? (rank << lg) : 0;
         const uint64_t width_mask = lg == 6 ? ~0ull : ((1ull << (1 << lg)) - 1ull);
         const uint64_t mine = need ? ((accepted >> first) & width_mask) : 0ull;
         const bool got = mine != 0;
         const int src = got ? first + __ffsll((unsigned long long)mine) - 1 : lane;
-        const double rx = __shfl(p.x, src, 64), ry = __shfl(p.y, src, 64), rz = __shfl(p.z, src, 64);
+        const double rx = shfl_d(p.x, src), ry = shfl_d(p.y, src), rz = shfl_d(p.z, src);
         if (need) result = mk(rx, ry, rz); // (its own candidate's coordinates when it got none: see above)
         if (got) {
             need = false;
@@ -233,7 +257,7 @@ __device__ __forceinline__ bool coop_random_in_unit_sphere(bool need, uint32_t p
         } else if (need) {
             base += 1u << lg;
         }
-        pending = __ballot(need);
+        pending = ballot(need);
     }
     return have;
 }
@@ -245,7 +269,7 @@ __device__ __forceinline__ void coop_random_in_unit_disk(bool need, uint32_t pix
                                                          uint32_t k1, int lane, Req4 *req, double &out_x,
                                                          double &out_y) {
     uint32_t base = 0;
-    uint64_t pending = __ballot(need);
+    uint64_t pending = ballot(need);
     while (pending != 0) {
         const int n = __popcll(pending);
         const int lg = n > 32 ? 0 : (n > 16 ? 1 : (n > 8 ? 2 : (n > 4 ? 3 : (n > 2 ? 4 : (n > 1 ? 5 : 6)))));
@@ -261,7 +285,7 @@ __device__ __forceinline__ void coop_random_in_unit_disk(bool need, uint32_t pix
                     base += 1u;
                 }
             }
-            pending = __ballot(need);
+            pending = ballot(need);
             continue;
         }
         const int rank = lane_rank(pending);
@@ -272,13 +296,13 @@ __device__ __forceinline__ void coop_random_in_unit_disk(bool need, uint32_t pix
         const Req4 r = req[serving ? j : 0];
         const u4 b = philox4x32(r.x, r.y, RT_RNG_LENS, r.w + (uint32_t)c, k0, k1);
         const double x = sym53(b.a, b.b), y = sym53(b.c, b.d);
-        const uint64_t accepted = __ballot(serving && x * x + y * y < 1.0);
+        const uint64_t accepted = ballot(serving && x * x + y * y < 1.0);
         const int first = need ? (rank << lg) : 0;
         const uint64_t width_mask = lg == 6 ? ~0ull : ((1ull << (1 << lg)) - 1ull);
         const uint64_t mine = need ? ((accepted >> first) & width_mask) : 0ull;
         const bool got = mine != 0;
         const int src = got ? first + __ffsll((unsigned long long)mine) - 1 : lane;
-        const double rx = __shfl(x, src, 64), ry = __shfl(y, src, 64);
+        const double rx = shfl_d(x, src), ry = shfl_d(y, src);
         if (got) {
             out_x = rx;
             out_y = ry;
@@ -286,7 +310,7 @@ __device__ __forceinline__ void coop_random_in_unit_disk(bool need, uint32_t pix
         } else if (need) {
             base += 1u << lg;
         }
-        pending = __ballot(need);
+        pending = ballot(need);
     }
 }
 
@@ -303,7 +327,7 @@ __device__ __forceinline__ void coop_random_in_unit_disk(bool need, uint32_t pix
 __device__ __forceinline__ double coop_noise_turbulence(bool need, d3 p, int depth, int perlin, const TraceArgs &A,
                                                         const Perlin *lds_perlin, int lane, NoiseSlots &S) {
     double turb = 0.0;
-    const uint64_t pending = __ballot(need);
+    const uint64_t pending = ballot(need);
     const int n = __popcll(pending);
     const int rank = lane_rank(pending);
     const int j = lane >> 3, o8 = lane & 7; // this lane works on request j of the round, octave o8 (+ 8 per pass)
@@ -320,7 +344,7 @@ __device__ __forceinline__ double coop_noise_turbulence(bool need, d3 p, int dep
         const bool serving = r0 + j < n;
         const int dj = serving ? S.depth[j] : 0;
         double accum = 0.0; // noise.rs:99
-        for (int ob = 0; __ballot(serving && ob < dj) != 0; ob += 8) { // one pass unless a texture has more than 8 octaves
+        for (int ob = 0; ballot(serving && ob < dj) != 0; ob += 8) { // one pass unless a texture has more than 8 octaves
             const int o = ob + o8;
             double term = 0.0;
             if (serving && o < dj) {
@@ -440,7 +464,15 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
     // boundary; the BVH variants keep one (their node array wants the LDS: three resident blocks
     // instead of two on the `random` scene) and a hand-out stops at the end of its batch.
     constexpr int NBUF = BVH ? 1 : 2;
-    __shared__ WaveLds<PRIMS == PRIMS_ANY, NBUF> lds_all[4];
+    // Two items in flight where it pays: the variants whose iterations are long (any primitive kind, BVH).  The rects-only
+    // and spheres-only variants gain under 1 % from it (their tail iterations are cheap: no hand-out, no batches, one sampler
+    // round) and lose 2 % to the bookkeeping, so they keep one item at a time and f64 sums.
+#if defined(RT_EXACT_DIV) || defined(RT_NO_OVERLAP)
+    constexpr bool OVERLAP = false;
+#else
+    constexpr bool OVERLAP = BVH || PRIMS == PRIMS_ANY;
+#endif
+    __shared__ WaveLds<TEXTURED, NBUF, OVERLAP> lds_all[4];
     // Dynamic LDS of a block: [BVH nodes | primitive table + texture table][Perlin gradients]; the host sizes it
     // (pool_dynamic_lds below) and says what is in it.
     extern __shared__ __align__(16) unsigned char dyn_lds[];
@@ -471,6 +503,16 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                         : (size_t)A.n_prims * sizeof(Prim) + (TEXTURED ? (size_t)A.n_textures * sizeof(Texture) : 0);
         if (TEXTURED && A.perlin_in_lds) at += sizeof(PerlinGradients);
         lens = reinterpret_cast<double (*)[64][2]>(dyn_lds + at) + (threadIdx.x >> 6) * NBUF;
+    }
+    // ... and the ray times of the batches, [NBUF][64] doubles per wave behind those: only a scene with a MovingSphere reads a
+    // ray's time (ray.rs:26-28), and without their 1 KB per wave more blocks fit a CU
+    double (*ray_times)[64] = nullptr;
+    if (PRIMS == PRIMS_ANY && A.time_lds) {
+        size_t at = BVH ? (size_t)A.bvh_lds_nodes * sizeof(BvhNode)
+                        : (size_t)A.n_prims * sizeof(Prim) + (TEXTURED ? (size_t)A.n_textures * sizeof(Texture) : 0);
+        if (TEXTURED && A.perlin_in_lds) at += sizeof(PerlinGradients);
+        if (A.lens_lds) at += (size_t)4 * NBUF * 64 * 2 * sizeof(double); // rt_device_types.h: pool_lens_lds_bytes
+        ray_times = reinterpret_cast<double (*)[64]>(dyn_lds + at) + (threadIdx.x >> 6) * NBUF;
     }
     // BVH nodes are staged in dynamic LDS when they fit (the host sets bvh_lds_nodes):
     // a traversal step is a dependent load, and ~100 steps at
@@ -506,12 +548,50 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
-    WaveLds<PRIMS == PRIMS_ANY, NBUF> &L = lds_all[threadIdx.x >> 6];
+    const int lane_of_wave = lane;
+    WaveLds<TEXTURED, NBUF, OVERLAP> &L = lds_all[threadIdx.x >> 6];
     unsigned int n_segments = 0, n_started = 0;
+    if (OVERLAP && lane < 3) L.ulc[lane] = A.cam.ulc[lane];
+
+    // SUMS AND OVERLAPPED ITEMS.  When the pool of an item is dry its last paths still take a dozen iterations to end, with
+    // ever fewer lanes tracing (`random`: 14 % of a wave's iterations ran at 14 lanes, cornell_box_boxes 13 % at 19, C4
+    // 6 % at 19; profiles/r04_region_cycles.txt).  With per-pixel sums kept as doubles the wave has to sit that tail out: the
+    // order in which an item's samples reach its sums — hence their rounding — must not depend on what else the wave is
+    // doing, or the frame would depend on which wave drew which item.  The OVERLAP variants keep the sums as INTEGERS
+    // instead (TraceArgs.sum_scale: the scene's radiance is bounded, so a sample fits a 52-bit fixed-point number) — exact,
+    // so their order does not matter — and draw the next item the moment the pool runs dry: two items are in flight, the
+    // lanes the old one frees start the new one's paths (cornell_box_boxes -5 %, `random` -2.5 % of the frame time; the
+    // frame is then also the same for strips that cut the item tiles: tests/test_gpu_overlap.py).  The other variants,
+    // and every RT_ARITH_REFERENCE kernel, add doubles and start the next item after the last path.  (A scene without a
+    // radiance bound — a colour above 1 on a scattering material — is given to the RT_ARITH_REFERENCE copy by the host.)
+    //
+    // The wave-uniform flags of this bookkeeping are bits of ONE integer and the tests on them integer compares: as `bool`s
+    // they lived in 64-bit lane masks, which the path loop's scalar register pressure sent to VGPR lanes — a dozen v_readlane
+    // per iteration.  They are also made opaque where the path loop tests them: a loop-invariant test is hoisted out of the
+    // loop AS A LANE MASK, with the same fate.
+    constexpr bool FIXED_SUMS = OVERLAP;
+#ifdef RT_EXACT_DIV
+    const uint32_t sum_scale_hi = 0u;
+#else
+    const uint32_t sum_scale_hi = (uint32_t)((unsigned long long)__double_as_longlong(A.sum_scale) >> 32); // 2^k: the lower half is 0
+#endif
+    // ---- the item entries are handed out of (slot `cur` of L.sum / L.info); the other slot may hold an item whose
+    // pool is dry and whose last paths are still in flight (`draining`)
+    // HAVE: slot `cur` holds an item (its pool may be dry); CUR: cur << 6, the slot bit as it sits in a lane's `spix`
+    enum : uint32_t { HAVE = 1u, DRAINING = 2u, QUEUE_DRY = 4u, CUR = 64u };
+    uint32_t state = 0u;
+    int smp0 = 0, n_valid = 0;
+    int tile_py0 = 0; // image row of the current tile's first row; -1: strips that cut tiles (the batches then take the long road)
+    uint32_t total = 0, next = 0, n_batches = 0, batches_done = 0;
+    uint32_t my_pixel = 0; // image index of this lane's pixel of the current item's tile
 
     RT_REGION_DECL
-    for (;;) {
-        // ---- next item for this wave
+    // Draws the wave's next item and sets slot `cur` up for it; false when the queue is dry.  (All 64 lanes.)
+    auto start_item = [&]() -> bool {
+        // (an opaque copy of the lane index: whatever of the code below depends on the lane alone would otherwise be computed
+        // once, in front of the loops, and parked in scratch memory across them — the plain variants have none)
+        int lane = lane_of_wave;
+        asm volatile("" : "+v"(lane));
         uint32_t item = 0;
         if (lane == 0) {
             item = atomicAdd(A.queue, 1u);
@@ -528,7 +608,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
             }
         }
         item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
-        if (item >= A.n_items) break;
+        if (item >= A.n_items) return false;
         // item -> (region, chunk, tile): regions in queue order, chunk-major inside a region (rt_device_types.h: Region)
         int region = 0, reg_tx0 = 0, reg_ty0 = 0, reg_ntx = A.tiles_x;
         uint32_t reg_tiles = (uint32_t)A.n_tiles, local = item;
@@ -545,21 +625,22 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
         const uint32_t tile = local - chunk * reg_tiles;
         const int ty = reg_ty0 + (int)(tile / (uint32_t)reg_ntx);
         const int tx = reg_tx0 + (int)(tile % (uint32_t)reg_ntx);
-        int smp0, n_smp; // the chunk's samples (chunk = index within this launch)
+        const int cur = (int)(state >> 6) & 1;
+        int n_smp; // the chunk's samples (chunk = index within this launch)
         {
             const RT_CONSTANT TraceArgs *K = kernargs_here();
             smp0 = K->chunk_start[A.chunk_base + (int)chunk];
             n_smp = K->chunk_start[A.chunk_base + (int)chunk + 1] - smp0;
         }
 
-        // ---- this lane's pixel of the tile (used for the pool table and the final store)
+        // ---- this lane's pixel of the tile (used for the pool table and the hand-out's pixel index)
         // (step_x/step_y > 1: the preview renderer, cpu_scaled.rs — the grid cell is the
         // top-left pixel of a block, the resolve pass fills the block)
         // Image row of the tile's first row.  With strips of a multiple of 8 rows (what every multi-GPU host here
         // uses) a tile lies inside ONE strip, so the owned-row -> image-row map is one scalar division per item;
         // other strip heights take the per-lane division.
         const bool rows_aligned = A.strip_count <= 1 || (A.strip_rows & 7) == 0;
-        int tile_py0 = ty * 8 * A.step_y;
+        tile_py0 = ty * 8 * A.step_y;
         if (A.strip_count > 1 && rows_aligned) {
             const int q = (ty * 8) / A.strip_rows; // wave-uniform
             tile_py0 = (q * A.strip_count + A.strip_index) * A.strip_rows + (ty * 8 - q * A.strip_rows);
@@ -570,420 +651,512 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
         if (!rows_aligned)
             my_py = ((my_vrow / A.strip_rows) * A.strip_count + A.strip_index) * A.strip_rows + my_vrow % A.strip_rows;
         const bool my_valid = my_px < A.cover_w && my_vrow < A.owned_rows && my_py < A.height;
-        const uint32_t my_pixel = (uint32_t)my_py * (uint32_t)A.width + (uint32_t)my_px;
-        const uint64_t valid_mask = __ballot(my_valid);
-        const int n_valid = __popcll(valid_mask);
+        my_pixel = (uint32_t)my_py * (uint32_t)A.width + (uint32_t)my_px;
+        const uint64_t valid_mask = ballot(my_valid);
+        n_valid = __popcll(valid_mask);
         {
             PathRng prng{my_pixel, RT_RNG_SAMPLE_PIXEL, A.seed_lo, A.seed_hi};
             u4 bj = prng.block(0, RT_RNG_PIXEL, 0);
             const RT_CONSTANT TraceArgs *K = kernargs_here();
             const double u = div_by((double)my_px + u53(bj.a, bj.b), (double)(A.width - 1), K->inv_width_m1); // cpu.rs:35-36
-            const d3 base = ld3(K->cam.ulc) + u * ld3(K->cam.horizontal);         // camera.rs:331, first two terms
-            L.base[lane][0] = base.x;
-            L.base[lane][1] = base.y;
-            L.base[lane][2] = base.z;
-            L.sum[lane][0] = 0.0;
-            L.sum[lane][1] = 0.0;
-            L.sum[lane][2] = 0.0;
+            if (OVERLAP) {
+                L.u[lane] = u;
+            } else {
+                const d3 base = ld3(K->cam.ulc) + u * ld3(K->cam.horizontal); // camera.rs:331, first two terms
+                L.base[lane][0] = base.x;
+                L.base[lane][1] = base.y;
+                L.base[lane][2] = base.z;
+            }
+            // fixed-point sums: a sample arrives as the bit pattern of (T * scale + 2^52), i.e. 0x433 << 52 plus the
+            // integer; the n_smp patterns' exponent fields are taken off here, once, instead of masked off every sample
+            const unsigned long long zero = FIXED_SUMS ? 0ull - (unsigned long long)n_smp * 0x4330000000000000ull : 0ull;
+            unsigned long long *sum = reinterpret_cast<unsigned long long *>(L.sum[cur * 64 + lane]);
+            sum[0] = zero;
+            sum[1] = zero;
+            sum[2] = zero;
             if (my_valid) L.pix_of[lane_rank(valid_mask)] = lane;
+            if (lane == 0) L.info[cur] = ItemInfo{(int)chunk, tx, ty, tile_py0, region, (int)reg_tiles, rows_aligned ? 1 : 0, 0};
         }
-        const uint32_t total = (uint32_t)n_valid * (uint32_t)n_smp; // paths in this item's pool
-        uint32_t next = 0;
-        // Pool entry w = (pixel w % n_valid of the tile, sample smp0 + w / n_valid).
-        auto entry_of = [&](uint32_t w, int &pix_out, int &py_out, uint32_t &pixel_out, uint32_t &sample_out) {
-            int s_off;
+        if (!rows_aligned) tile_py0 = -1;
+        total = (uint32_t)n_valid * (uint32_t)n_smp; // paths in this item's pool
+        next = 0;
+        n_batches = (total + 63u) >> 6;
+        batches_done = 0;
+        return true;
+    };
+    // The item of slot `s` has no path left: its sums go to its own slice of `partial` (or the launch finishes the tile's
+    // pixels itself: deliver_item).  (All 64 lanes.)
+    auto finish_item = [&](int s) {
+        int lane = lane_of_wave;
+        asm volatile("" : "+v"(lane));
+        const ItemInfo I = L.info[s];
+        const int chunk = __builtin_amdgcn_readfirstlane(I.chunk), f_tx = __builtin_amdgcn_readfirstlane(I.tx),
+                  f_ty = __builtin_amdgcn_readfirstlane(I.ty), f_py0 = __builtin_amdgcn_readfirstlane(I.tile_py0);
+        const bool f_aligned = __builtin_amdgcn_readfirstlane(I.rows_aligned) != 0;
+        const int f_px = (f_tx * 8 + (lane & 7)) * A.step_x;
+        const int f_vrow = f_ty * 8 + (lane >> 3);
+        int f_py = f_py0 + (lane >> 3) * A.step_y;
+        if (!f_aligned) f_py = ((f_vrow / A.strip_rows) * A.strip_count + A.strip_index) * A.strip_rows + f_vrow % A.strip_rows;
+        const bool f_valid = f_px < A.cover_w && f_vrow < A.owned_rows && f_py < A.height;
+        double s0 = L.sum[s * 64 + lane][0], s1 = L.sum[s * 64 + lane][1], s2 = L.sum[s * 64 + lane][2];
+        if (FIXED_SUMS) { // the integers, rounded ONCE to the nearest double; the scale is a power of two
+            const double unscale = kernargs_here()->sum_unscale;
+            s0 = (double)(unsigned long long)__double_as_longlong(s0) * unscale;
+            s1 = (double)(unsigned long long)__double_as_longlong(s1) * unscale;
+            s2 = (double)(unsigned long long)__double_as_longlong(s2) * unscale;
+        }
+        if (A.deliver_out == nullptr) {
+            if (f_valid) {
+                // slice row = row of the launch's owned-row grid (a share's slices hold its own rows only)
+                const size_t in_slice = (size_t)f_vrow * (size_t)A.width + (size_t)f_px;
+                double *dst = A.partial + ((size_t)(A.chunk_base + chunk) * (size_t)A.slice_rows * (size_t)A.width + in_slice) * 3;
+                dst[0] = s0;
+                dst[1] = s1;
+                dst[2] = s2;
+            }
+        } else {
+            deliver_item(kernargs_here(), s0, s1, s2, f_valid, chunk, f_tx, f_ty, f_py0, f_aligned, __builtin_amdgcn_readfirstlane(I.region),
+                         (uint32_t)__builtin_amdgcn_readfirstlane(I.reg_tiles));
+        }
+    };
+    // Pool entry w of the current item = (pixel w % n_valid of the tile, sample smp0 + w / n_valid).
+    auto entry_of = [&](uint32_t w, int &py_out, uint32_t &pixel_out, uint32_t &sample_out) { // (all 64 lanes: a lane shuffle)
+        int s_off, pix;
+        if (n_valid == 64) {
+            pix = (int)(w & 63u);
+            s_off = (int)(w >> 6);
+        } else {
+            s_off = (int)(w / (uint32_t)n_valid);
+            pix = L.pix_of[w - (uint32_t)s_off * (uint32_t)n_valid];
+        }
+        // lane p of the wave holds the image index of pixel p of the tile (my_pixel); the image row follows from the
+        // tile's first row — or, with strips that cut tiles (tile_py0 < 0), from the parked tile row
+        pixel_out = (uint32_t)shfl_i((int)my_pixel, pix);
+        py_out = tile_py0 + (pix >> 3) * A.step_y;
+        if (tile_py0 < 0) {
+            const int vrow = __builtin_amdgcn_readfirstlane(L.info[(state >> 6) & 1u].ty) * 8 + (pix >> 3);
+            py_out = ((vrow / A.strip_rows) * A.strip_count + A.strip_index) * A.strip_rows + vrow % A.strip_rows;
+        }
+        sample_out = (uint32_t)(smp0 + s_off);
+    };
+    // REGENERATION BATCHES.  A lane that starts a new path needs the path's camera
+    // sample: the vertical jitter and ray time (one Philox block) and the lens disk (a
+    // rejection loop).  Only ~16 of 64 lanes start a path in a given iteration, so doing
+    // this at the hand-out runs ~120 instructions at 25 % lane use.  Entries leave the pool
+    // in index order, so the wave instead draws the samples of 64 consecutive entries at
+    // once — every lane busy — into LDS, two batches ahead of `next`.  (The buffers belong to the current item: an item
+    // that still has paths in flight when the next one starts has handed out all its entries.)
+    auto prepare_batch = [&](uint32_t b) {
+        const RT_CONSTANT TraceArgs *K = kernargs_here();
+        const uint32_t w = b * 64u + (uint32_t)lane;
+        const bool in_pool = w < total;
+        int py_b = 0;
+        uint32_t pixel_b = 0, sample_b = 0;
+        entry_of(w, py_b, pixel_b, sample_b); // (entries behind the pool's end: values nobody reads)
+        const u4 bc = philox4x32(pixel_b, sample_b, RT_RNG_CAMERA, 0u, A.seed_lo, A.seed_hi);
+        const int buf = (int)(b & (uint32_t)(NBUF - 1));
+        L.v[buf][lane] = div_by((double)py_b + u53(bc.a, bc.b), (double)(A.height - 1), K->inv_height_m1); // cpu.rs:39-40
+        // camera.rs:335: the ray's time, second double of the same block (MovingSphere reads it)
+        if (PRIMS == PRIMS_ANY && ray_times != nullptr) ray_times[buf][lane] = K->cam.time_a + (K->cam.time_b - K->cam.time_a) * u53(bc.c, bc.d);
+        // camera.rs:327: aperture 0 multiplies the disk by 0, so its draws are dead and skipped
+        if (K->cam.lens_radius != 0.0) {
+            double lx = 0.0, ly = 0.0;
+            coop_random_in_unit_disk(in_pool, pixel_b, sample_b, A.seed_lo, A.seed_hi, lane, L.scratch.req, lx, ly);
+            lens[buf][lane][0] = lx;
+            lens[buf][lane][1] = ly;
+        }
+    };
+
+    // ---- path state of this lane (it outlives the items: a lane's path may belong to either slot)
+    bool alive = false;
+    int spix = 0;         // slot of the item the current path belongs to << 6 | its pixel of that item's tile (lane order)
+    PathRng rng{0, 0, A.seed_lo, A.seed_hi};
+    d3 o = mk(0, 0, 0), d = o, T = o;
+    uint32_t seg = 0;
+    double ray_time = 0.0; // ray.rs:26-28; scattered rays inherit it (e.g. lambertian.rs:35)
+    // A lane whose hit needs a random_in_unit_sphere sample that the wave has not
+    // found yet stays `waiting` (it keeps its hit below and skips tracing) until a
+    // later iteration's sampler rounds reach its accepted candidate.
+    bool waiting = false;
+    uint32_t cand_base = 0;   // first untested candidate of the open request
+    bool is_lambert = false;  // material of the open hit (else Metal)
+    // the open hit: its point takes the ray origin's place (`o` is dead once the hit record exists) and its
+    // attenuation goes into T at once, so neither is carried as extra state while the lane waits
+    d3 hit_normal = o;
+    double fuzz = 0.0;
+
+    for (;;) {
+        // ---- the items in flight (wave-uniform; out here, not in the path loop below: with this code inside it the path
+        // state was copied from register to register around it in every iteration — C3 5.78 -> 6.84 vector instructions
+        // per segment)
+        if ((state & (HAVE | DRAINING)) == HAVE && next >= total) { // the pool is dry: what is in flight of it drains in the other slot
+            state ^= HAVE | DRAINING | (OVERLAP ? CUR : 0u);
+            total = next = n_batches = batches_done = 0; // (no pool: the hand-out below finds nothing to do)
+        }
+        // (without OVERLAP there is one slot, and whatever is in flight belongs to the draining item)
+        if ((state & DRAINING) != 0u && ballot(alive && (!OVERLAP || (((uint32_t)spix ^ state) & CUR) != 0u)) == 0) { // the last path of the draining item has ended
+            finish_item(OVERLAP ? (int)((state ^ CUR) >> 6) & 1 : 0);
+            state &= ~DRAINING;
+        }
+        if ((state & (HAVE | QUEUE_DRY)) == 0u && (FIXED_SUMS || (state & DRAINING) == 0u)) state |= start_item() ? HAVE : QUEUE_DRY;
+        if ((state & (HAVE | DRAINING)) == 0u) break; // the queue is dry and nothing is in flight
+        RT_REGION(0); // item setup / end
+        if (!OVERLAP) {
+            // one item at a time: no path is in flight here.  Saying so — every lane's path state is set anew — ends the
+            // state's live ranges at the loop's exit: across the item code above they would otherwise hold their registers
+            // (the plain variants: 77 -> 80 VGPRs and 64 bytes of scratch).
+            alive = false;
+            waiting = false;
+            is_lambert = false;
+            spix = 0;
+            rng.pixel = rng.sample = 0;
+            o = d = T = hit_normal = mk(0, 0, 0);
+            seg = cand_base = 0;
+            ray_time = fuzz = 0.0;
+        }
+        // ---- the path loop: until the pool runs dry or the draining item's last path ends
+        for (;;) {
+        // ---- camera samples for the entries about to leave the pool (whole wave, see above)
+        while (batches_done < n_batches && batches_done <= (next >> 6) + (uint32_t)(NBUF - 1)) prepare_batch(batches_done++);
+        RT_REGION(1); // batches
+        // ---- hand pool entries to the lanes without a path (ballot + prefix count)
+        if (next < total) {
+            const uint64_t idle = ballot(!alive);
+            const uint32_t w = next + (uint32_t)lane_rank(idle);
+            // entries whose camera samples are in LDS: all of them with two buffers, the current batch with one
+            const uint32_t ready = NBUF == 2 ? total : min(total, batches_done << 6);
+            next = min(next + (uint32_t)__popcll(idle), ready);
+            // entry_of(w) without the pixel arithmetic: lane p of the wave holds pixel p's index in the image
+            // (my_pixel), so the entry's comes by a lane shuffle — which every lane has to take part in, hence
+            // out here (the lanes that have a path compute an entry nobody reads)
+            int s_off, pix_new;
             if (n_valid == 64) {
-                pix_out = (int)(w & 63u);
+                pix_new = (int)(w & 63u);
                 s_off = (int)(w >> 6);
             } else {
                 s_off = (int)(w / (uint32_t)n_valid);
-                pix_out = L.pix_of[w - (uint32_t)s_off * (uint32_t)n_valid];
+                pix_new = L.pix_of[w - (uint32_t)s_off * (uint32_t)n_valid];
             }
-            const int px = (tx * 8 + (pix_out & 7)) * A.step_x;
-            py_out = tile_py0 + (pix_out >> 3) * A.step_y;
-            if (!rows_aligned) {
-                const int vrow = ty * 8 + (pix_out >> 3);
-                py_out = ((vrow / A.strip_rows) * A.strip_count + A.strip_index) * A.strip_rows + vrow % A.strip_rows;
-            }
-            pixel_out = (uint32_t)py_out * (uint32_t)A.width + (uint32_t)px;
-            sample_out = (uint32_t)(smp0 + s_off);
-        };
-        // REGENERATION BATCHES.  A lane that starts a new path needs the path's camera
-        // sample: the vertical jitter and ray time (one Philox block) and the lens disk (a
-        // rejection loop).  Only ~16 of 64 lanes start a path in a given iteration, so doing
-        // this at the hand-out runs ~120 instructions at 25 % lane use.  Entries leave the pool
-        // in index order, so the wave instead draws the samples of 64 consecutive entries at
-        // once — every lane busy — into LDS, two batches ahead of `next`.
-        const uint32_t n_batches = (total + 63u) >> 6;
-        uint32_t batches_done = 0;
-        auto prepare_batch = [&](uint32_t b) {
-            const RT_CONSTANT TraceArgs *K = kernargs_here();
-            const uint32_t w = b * 64u + (uint32_t)lane;
-            const bool in_pool = w < total;
-            int pix_b = 0, py_b = 0;
-            uint32_t pixel_b = 0, sample_b = 0;
-            if (in_pool) entry_of(w, pix_b, py_b, pixel_b, sample_b);
-            const u4 bc = philox4x32(pixel_b, sample_b, RT_RNG_CAMERA, 0u, A.seed_lo, A.seed_hi);
-            const int buf = (int)(b & (uint32_t)(NBUF - 1));
-            L.v[buf][lane] = div_by((double)py_b + u53(bc.a, bc.b), (double)(A.height - 1), K->inv_height_m1); // cpu.rs:39-40
-            // camera.rs:335: the ray's time, second double of the same block (MovingSphere reads it)
-            if (PRIMS == PRIMS_ANY) L.time[buf][lane] = K->cam.time_a + (K->cam.time_b - K->cam.time_a) * u53(bc.c, bc.d);
-            // camera.rs:327: aperture 0 multiplies the disk by 0, so its draws are dead and skipped
-            if (K->cam.lens_radius != 0.0) {
-                double lx = 0.0, ly = 0.0;
-                coop_random_in_unit_disk(in_pool, pixel_b, sample_b, A.seed_lo, A.seed_hi, lane, L.scratch.req, lx, ly);
-                lens[buf][lane][0] = lx;
-                lens[buf][lane][1] = ly;
-            }
-        };
-
-        RT_REGION(0); // item setup
-        // ---- path state of this lane
-        bool alive = false;
-        int pix = 0;          // pixel of the tile (lane order) the current path belongs to
-        PathRng rng{0, 0, A.seed_lo, A.seed_hi};
-        d3 o = mk(0, 0, 0), d = o, T = o;
-        uint32_t seg = 0;
-        double ray_time = 0.0; // ray.rs:26-28; scattered rays inherit it (e.g. lambertian.rs:35)
-        // A lane whose hit needs a random_in_unit_sphere sample that the wave has not
-        // found yet stays `waiting` (it keeps its hit below and skips tracing) until a
-        // later iteration's sampler rounds reach its accepted candidate.
-        bool waiting = false;
-        uint32_t cand_base = 0;   // first untested candidate of the open request
-        bool is_lambert = false;  // material of the open hit (else Metal)
-        // the open hit: its point takes the ray origin's place (`o` is dead once the hit record exists) and its
-        // attenuation goes into T at once, so neither is carried as extra state while the lane waits
-        d3 hit_normal = o;
-        double fuzz = 0.0;
-
-        for (;;) {
-            // ---- camera samples for the entries about to leave the pool (whole wave, see above)
-            while (batches_done < n_batches && batches_done <= (next >> 6) + (uint32_t)(NBUF - 1)) prepare_batch(batches_done++);
-            RT_REGION(1); // batches
-            // ---- hand pool entries to the lanes without a path (ballot + prefix count)
-            if (next < total) {
-                const uint64_t idle = __ballot(!alive);
-                const uint32_t w = next + (uint32_t)lane_rank(idle);
-                // entries whose camera samples are in LDS: all of them with two buffers, the current batch with one
-                const uint32_t ready = NBUF == 2 ? total : min(total, batches_done << 6);
-                next = min(next + (uint32_t)__popcll(idle), ready);
-                // entry_of(w) without the pixel arithmetic: lane p of the wave holds pixel p's index in the image
-                // (my_pixel), so the entry's comes by a lane shuffle — which every lane has to take part in, hence
-                // out here (the lanes that have a path compute an entry nobody reads)
-                int s_off, pix_new;
-                if (n_valid == 64) {
-                    pix_new = (int)(w & 63u);
-                    s_off = (int)(w >> 6);
-                } else {
-                    s_off = (int)(w / (uint32_t)n_valid);
-                    pix_new = L.pix_of[w - (uint32_t)s_off * (uint32_t)n_valid];
+            const uint32_t pixel_new = (uint32_t)shfl_i((int)my_pixel, pix_new);
+            if (!alive && w < ready) { // cpu.rs:39-40 + camera.rs:326-337
+                spix = (int)(state & CUR) | pix_new;
+                rng.pixel = pixel_new;
+                rng.sample = (uint32_t)(smp0 + s_off);
+                const RT_CONSTANT TraceArgs *K = kernargs_here();
+                const int buf = (int)((w >> 6) & (uint32_t)(NBUF - 1)), slot = (int)(w & 63u);
+                const double v = L.v[buf][slot];
+                const d3 co = ld3(K->cam.origin);
+                o = co;
+                if (OVERLAP) d = (ld3(L.ulc) + L.u[pix_new] * ld3(K->cam.horizontal)) - v * ld3(K->cam.vertical) - co; // camera.rs:331
+                else d = ld3(L.base[pix_new]) - v * ld3(K->cam.vertical) - co;
+                const double lr = K->cam.lens_radius;
+                if (lr != 0.0) {
+                    const d3 offset = ld3(K->cam.right) * (lens[buf][slot][0] * lr) + ld3(K->cam.up) * (lens[buf][slot][1] * lr);
+                    o = co + offset;
+                    d = d - offset;
                 }
-                const uint32_t pixel_new = (uint32_t)__shfl((int)my_pixel, pix_new, 64);
-                if (!alive && w < ready) { // cpu.rs:39-40 + camera.rs:326-337
-                    pix = pix_new;
-                    rng.pixel = pixel_new;
-                    rng.sample = (uint32_t)(smp0 + s_off);
-                    const RT_CONSTANT TraceArgs *K = kernargs_here();
-                    const int buf = (int)((w >> 6) & (uint32_t)(NBUF - 1)), slot = (int)(w & 63u);
-                    const double v = L.v[buf][slot];
-                    const d3 co = ld3(K->cam.origin);
-                    o = co;
-                    d = ld3(L.base[pix]) - v * ld3(K->cam.vertical) - co;
-                    const double lr = K->cam.lens_radius;
-                    if (lr != 0.0) {
-                        const d3 offset = ld3(K->cam.right) * (lens[buf][slot][0] * lr) + ld3(K->cam.up) * (lens[buf][slot][1] * lr);
-                        o = co + offset;
-                        d = d - offset;
-                    }
-                    if (PRIMS == PRIMS_ANY) ray_time = L.time[buf][slot];
-                    T = mk(1.0, 1.0, 1.0);
-                    seg = 0;
-                    alive = true;
-                    ++n_started;
-                }
+                if (PRIMS == PRIMS_ANY && ray_times != nullptr) ray_time = ray_times[buf][slot];
+                T = mk(1.0, 1.0, 1.0);
+                seg = 0;
+                alive = true;
+                ++n_started;
             }
-            RT_REGION(2); // hand-out + primary ray
-            if (__ballot(alive) == 0) break; // pool dry and nothing in flight
-
-            // ---- one ray_color level for every lane with a path
-            // A path that ends here adds its throughput T (times what it ran into) to its pixel: T is dead
-            // afterwards, so the product is formed in place.
-            bool ended = false;
-            bool scattered = false;  // the path got a new ray this iteration (depth check below)
-            bool finish = false;     // Lambertian / Metal hit whose direction can be completed now
-            int noise_tex = -1;      // Noise texture this lane's hit wants (evaluated by the whole wave below)
-            RT_LANES(__popcll(__ballot(alive && !waiting)), next >= total);
-            if (alive && !waiting) {
-                if (A.max_depth <= 0) { // renderer.rs:48-55 with max_depth 0
-                    ended = true;
+        }
+        RT_REGION(2); // hand-out + primary ray
+        // (one item at a time: the loop ends when the pool is dry and nothing is in flight — a scalar test on a ballot.
+        // The OVERLAP variants leave at the bottom instead.)
+        if (!OVERLAP && ballot(alive) == 0) break;
+        // ---- one ray_color level for every lane with a path
+        // A path that ends here adds its throughput T (times what it ran into) to its pixel: T is dead
+        // afterwards, so the product is formed in place.
+        bool ended = false;
+        bool scattered = false;  // the path got a new ray this iteration (depth check below)
+        bool finish = false;     // Lambertian / Metal hit whose direction can be completed now
+        int noise_tex = -1;      // Noise texture this lane's hit wants (evaluated by the whole wave below)
+        RT_LANES(__popcll(ballot(alive && !waiting)), next >= total);
+        if (alive && !waiting) {
+            int max_depth = A.max_depth;
+            asm volatile("" : "+s"(max_depth)); // (opaque: hoisted out of the loop the test lives in a lane mask that is spilled)
+            if (max_depth <= 0) { // renderer.rs:48-55 with max_depth 0
+                ended = true;
+            } else {
+                ++n_segments;
+                double best_t = __builtin_inf(); // closest hit, t in [0.001, inf) (renderer.rs:58)
+                int best = -1, best_aux = 0;
+                const d3 inv_d = rcp3(d);
+                const double inv_a = PRIMS == PRIMS_RECTS ? 0.0 : rcp_f64(len2(d));
+                if (BVH) {
+#ifdef RT_PROFILE_REGIONS
+                    unsigned walk[2] = {0, 0};
+                    unsigned *walk_stats = walk;
+#else
+                    unsigned *walk_stats = nullptr;
+#endif
+#ifdef RT_PROFILE_REGIONS
+                    auto walk_mark = [&](int k) { RT_REGION(k); };
+#else
+                    const NoMark walk_mark;
+#endif
+                    if (lds_nodes != nullptr)
+                        closest_hit_bvh<PRIMS>(A, lds_nodes, o, d, inv_d, inv_a, ray_time, 0.001, best_t, best, best_aux, walk_stats, walk_mark);
+                    else
+                        closest_hit_bvh<PRIMS>(A, bvh_nodes_for(A, d), o, d, inv_d, inv_a, ray_time, 0.001, best_t, best, best_aux, walk_stats, walk_mark);
+#ifdef RT_PROFILE_REGIONS
+                    atomicAdd(&rt_t_[37], (unsigned long long)walk[0]); // per-lane totals (LDS atomics)
+                    atomicAdd(&rt_t_[38], (unsigned long long)walk[1]);
+#endif
                 } else {
-                    ++n_segments;
-                    double best_t = __builtin_inf(); // closest hit, t in [0.001, inf) (renderer.rs:58)
-                    int best = -1, best_aux = 0;
-                    const d3 inv_d = rcp3(d);
-                    const double inv_a = PRIMS == PRIMS_RECTS ? 0.0 : rcp_f64(len2(d));
-                    if (BVH) {
-#ifdef RT_PROFILE_REGIONS
-                        unsigned walk[2] = {0, 0};
-                        unsigned *walk_stats = walk;
-#else
-                        unsigned *walk_stats = nullptr;
-#endif
-#ifdef RT_PROFILE_REGIONS
-                        auto walk_mark = [&](int k) { RT_REGION(k); };
-#else
-                        const NoMark walk_mark;
-#endif
-                        if (lds_nodes != nullptr)
-                            closest_hit_bvh<PRIMS>(A, lds_nodes, o, d, inv_d, inv_a, ray_time, 0.001, best_t, best, best_aux, walk_stats, walk_mark);
-                        else
-                            closest_hit_bvh<PRIMS>(A, bvh_nodes_for(A, d), o, d, inv_d, inv_a, ray_time, 0.001, best_t, best, best_aux, walk_stats, walk_mark);
-#ifdef RT_PROFILE_REGIONS
-                        atomicAdd(&rt_t_[37], (unsigned long long)walk[0]); // per-lane totals (LDS atomics)
-                        atomicAdd(&rt_t_[38], (unsigned long long)walk[1]);
-#endif
-                    } else {
-                        auto test = [&](const Prim &P, int i) {
+                    auto test = [&](const Prim &P, int i) {
+                        double t;
+                        int aux;
+                        if (prim_t<PRIMS>(P, o, d, inv_d, inv_a, ray_time, 0.001, best_t, t, aux)) {
+                            best_t = t;
+                            best = i;
+                            best_aux = aux;
+                        }
+                    };
+                    // two records per scalar-load wait: the table's latency is paid n/2 times, not n
+                    // (C3 +2.8 %, C2 +3.8 %; three per wait run out of SGPRs and lose it again)
+                    if (PRIMS != PRIMS_SPHERES) {
+                        // The table is grouped (rect_end, sphere_end): one straight-line test per group, the plane a
+                        // compile-time constant, instead of a scalar switch on the kind of every record.
+                        auto test_plane = [&](auto axis, const Prim &P, int i) {
                             double t;
-                            int aux;
-                            if (prim_t<PRIMS>(P, o, d, inv_d, inv_a, ray_time, 0.001, best_t, t, aux)) {
+                            if (rect_t<true>(decltype(axis)::value, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, 0.001, best_t, t)) {
                                 best_t = t;
                                 best = i;
-                                best_aux = aux;
                             }
                         };
-                        // two records per scalar-load wait: the table's latency is paid n/2 times, not n
-                        // (C3 +2.8 %, C2 +3.8 %; three per wait run out of SGPRs and lose it again)
-                        if (PRIMS != PRIMS_SPHERES) {
-                            // The table is grouped (rect_end, sphere_end): one straight-line test per group, the plane a
-                            // compile-time constant, instead of a scalar switch on the kind of every record.
-                            auto test_plane = [&](auto axis, const Prim &P, int i) {
+                        auto group = [&](auto axis, int begin, int end) {
+                            int i = begin;
+                            for (; i + 1 < end; i += 2) {
+                                const Prim pa = load_prim_uniform(A.prims, i), pb = load_prim_uniform(A.prims, i + 1);
+                                test_plane(axis, pa, i);
+                                test_plane(axis, pb, i + 1);
+                            }
+                            if (i < end) test_plane(axis, load_prim_uniform(A.prims, i), i);
+                        };
+                        // the group bounds are re-read from the kernel arguments HERE (kernargs_here): hoisted out of the
+                        // path loop their emptiness tests sit in SGPR pairs that the allocator parks in VGPR lanes, and
+                        // every iteration pays a v_readlane (4.3 SIMD cycles of the saturated vector pipe) per half of them
+                        const RT_CONSTANT TraceArgs *KB = kernargs_here();
+                        const int end_xy = KB->rect_end[0], end_xz = KB->rect_end[1], end_yz = KB->rect_end[2];
+                        group(std::integral_constant<int, 2>(), 0, end_xy);       // XY
+                        group(std::integral_constant<int, 1>(), end_xy, end_xz);  // XZ
+                        group(std::integral_constant<int, 0>(), end_xz, end_yz);  // YZ
+                        if (PRIMS == PRIMS_ANY) {
+                            int i = end_yz;
+                            for (; i < A.sphere_end; ++i) { // plain spheres: sphere.rs:39-59, no switch, no wrapper
                                 double t;
-                                if (rect_t<true>(decltype(axis)::value, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, 0.001, best_t, t)) {
+                                int aux;
+                                if (prim_t<PRIMS_SPHERES>(load_prim_uniform(A.prims, i), o, d, inv_d, inv_a, ray_time, 0.001, best_t, t, aux)) {
                                     best_t = t;
                                     best = i;
+                                    best_aux = 0;
                                 }
-                            };
-                            auto group = [&](auto axis, int begin, int end) {
-                                int i = begin;
-                                for (; i + 1 < end; i += 2) {
-                                    const Prim pa = load_prim_uniform(A.prims, i), pb = load_prim_uniform(A.prims, i + 1);
-                                    test_plane(axis, pa, i);
-                                    test_plane(axis, pb, i + 1);
-                                }
-                                if (i < end) test_plane(axis, load_prim_uniform(A.prims, i), i);
-                            };
-                            // the group bounds are re-read from the kernel arguments HERE (kernargs_here): hoisted out of the
-                            // path loop their emptiness tests sit in SGPR pairs that the allocator parks in VGPR lanes, and
-                            // every iteration pays a v_readlane (4.3 SIMD cycles of the saturated vector pipe) per half of them
-                            const RT_CONSTANT TraceArgs *KB = kernargs_here();
-                            const int end_xy = KB->rect_end[0], end_xz = KB->rect_end[1], end_yz = KB->rect_end[2];
-                            group(std::integral_constant<int, 2>(), 0, end_xy);       // XY
-                            group(std::integral_constant<int, 1>(), end_xy, end_xz);  // XZ
-                            group(std::integral_constant<int, 0>(), end_xz, end_yz);  // YZ
-                            if (PRIMS == PRIMS_ANY) {
-                                int i = end_yz;
-                                for (; i < A.sphere_end; ++i) { // plain spheres: sphere.rs:39-59, no switch, no wrapper
-                                    double t;
-                                    int aux;
-                                    if (prim_t<PRIMS_SPHERES>(load_prim_uniform(A.prims, i), o, d, inv_d, inv_a, ray_time, 0.001, best_t, t, aux)) {
-                                        best_t = t;
-                                        best = i;
-                                        best_aux = 0;
-                                    }
-                                }
-                                for (; i < KB->box_end; ++i) { // boxes, bare or wrapped: box.rs:82-101 as three slabs, no switch
-                                    double t;
-                                    int side;
-                                    if (box_t(load_prim_uniform(A.prims, i), o, d, inv_d, 0.001, best_t, t, side)) {
-                                        best_t = t;
-                                        best = i;
-                                        best_aux = side;
-                                    }
-                                }
-                                for (; i < A.n_prims; ++i) test(load_prim_uniform(A.prims, i), i); // moving spheres, wrapped rects and spheres
                             }
-                        } else {
-                            int i = 0;
-                            for (; i + 1 < A.n_prims; i += 2) {
-                                const Prim pa = load_prim_uniform(A.prims, i), pb = load_prim_uniform(A.prims, i + 1);
-                                test(pa, i);
-                                test(pb, i + 1);
+                            for (; i < KB->box_end; ++i) { // boxes, bare or wrapped: box.rs:82-101 as three slabs, no switch
+                                double t;
+                                int side;
+                                if (box_t(load_prim_uniform(A.prims, i), o, d, inv_d, 0.001, best_t, t, side)) {
+                                    best_t = t;
+                                    best = i;
+                                    best_aux = side;
+                                }
                             }
-                            if (i < A.n_prims) test(load_prim_uniform(A.prims, i), i);
+                            for (; i < A.n_prims; ++i) test(load_prim_uniform(A.prims, i), i); // moving spheres, wrapped rects and spheres
+                        }
+                    } else {
+                        int i = 0;
+                        for (; i + 1 < A.n_prims; i += 2) {
+                            const Prim pa = load_prim_uniform(A.prims, i), pb = load_prim_uniform(A.prims, i + 1);
+                            test(pa, i);
+                            test(pb, i + 1);
+                        }
+                        if (i < A.n_prims) test(load_prim_uniform(A.prims, i), i);
+                    }
+                }
+                RT_REGION(3); // closest hit
+                if (best < 0) { // background_color.rs:27-33 / :45-48
+                    const RT_CONSTANT TraceArgs *K = kernargs_here();
+                    d3 bgc = ld3(K->bg.top);
+                    if (K->bg.kind == RT_BG_SKY) {
+                        const double t = 0.5 * (unit_fast(d).y + 1.0);
+                        bgc = (1.0 - t) * bgc + t * ld3(K->bg.bottom);
+                    }
+                    T = T * bgc;
+                    ended = true;
+                } else {
+                    const Prim &P = BVH ? A.prims[best] : lds_prims[best];
+                    const Material &M = P.mat;
+                    const Hit h = prim_hit_record<PRIMS, TEXTURED, true>(P, o, d, ray_time, best_t, best_aux, M.needs_uv != 0);
+                    const int kind = M.kind;
+                    RT_REGION(8); // hit record
+#ifdef RT_PROFILE_REGIONS
+                    { // how many lanes of an iteration look up a Noise texture together?
+                        const int n_noise = __popcll(ballot(TEXTURED && M.tex_kind == RT_TEX_NOISE));
+                        if (n_noise > 0 && lane_rank(ballot(1)) == 0) {
+                            rt_t_[35] += 1;
+                            rt_t_[36] += (unsigned long long)n_noise;
                         }
                     }
-                    RT_REGION(3); // closest hit
-                    if (best < 0) { // background_color.rs:27-33 / :45-48
-                        const RT_CONSTANT TraceArgs *K = kernargs_here();
-                        d3 bgc = ld3(K->bg.top);
-                        if (K->bg.kind == RT_BG_SKY) {
-                            const double t = 0.5 * (unit_fast(d).y + 1.0);
-                            bgc = (1.0 - t) * bgc + t * ld3(K->bg.bottom);
-                        }
-                        T = T * bgc;
-                        ended = true;
-                    } else {
-                        const Prim &P = BVH ? A.prims[best] : lds_prims[best];
-                        const Material &M = P.mat;
-                        const Hit h = prim_hit_record<PRIMS, TEXTURED, true>(P, o, d, ray_time, best_t, best_aux, M.needs_uv != 0);
-                        const int kind = M.kind;
-                        RT_REGION(8); // hit record
-#ifdef RT_PROFILE_REGIONS
-                        { // how many lanes of an iteration look up a Noise texture together?
-                            const int n_noise = __popcll(__ballot(TEXTURED && M.tex_kind == RT_TEX_NOISE));
-                            if (n_noise > 0 && lane_rank(__ballot(1)) == 0) {
-                                rt_t_[35] += 1;
-                                rt_t_[36] += (unsigned long long)n_noise;
-                            }
-                        }
 #endif
-                        // Texture::value once for every material that has one (light, Lambertian, Metal):
-                        // one copy of the texture code, shared by the lanes of all three
-                        // (variants without SPECULAR hold lights and Lambertians only: the host picks SPECULAR
-                        // whenever a Metal or Dialectric exists)
-                        if (!SPECULAR || kind != RT_MAT_DIELECTRIC) {
-                            d3 tex;
-                            if (!TEXTURED || M.tex_kind == RT_TEX_SOLID_COLOR) tex = ld3(M.color); // solid_color.rs:24-28
-                            else tex = texture_value_deferred(A, BVH ? A.textures : lds_textures, M.texture, h.u, h.v, h.point, noise_tex, h.uv_approx,
-                                                              // sphere.rs:20-27 in f64 from the outward normal (the face normal, un-flipped: exact)
-                                                              [&] { return sphere_uv(h.front ? h.normal : -h.normal); });
-                            // emission (the path ends) or attenuation, one copy for all three; a Noise colour arrives below
-                            if (!TEXTURED || noise_tex < 0) T = T * tex;
-                        }
-                        RT_REGION(9); // texture, step 1
-                        // With four arms, what every material does with the hit goes before the switch: a value
-                        // assigned in one arm only costs every arm a copy where they meet (C2 -1.7 %; with the two
-                        // arms of the other variants the same hoist costs C3 1 %).  A light ends the path, the point
-                        // of a Noise light is read below; hit_normal and fuzz are Metal's, dead for the others.
-                        const d3 d_in = d;
-                        if (SPECULAR) {
+                    // Texture::value once for every material that has one (light, Lambertian, Metal):
+                    // one copy of the texture code, shared by the lanes of all three
+                    // (variants without SPECULAR hold lights and Lambertians only: the host picks SPECULAR
+                    // whenever a Metal or Dialectric exists)
+                    if (!SPECULAR || kind != RT_MAT_DIELECTRIC) {
+                        d3 tex;
+                        if (!TEXTURED || M.tex_kind == RT_TEX_SOLID_COLOR) tex = ld3(M.color); // solid_color.rs:24-28
+                        else tex = texture_value_deferred(A, BVH ? A.textures : lds_textures, M.texture, h.u, h.v, h.point, noise_tex, h.uv_approx,
+                                                          // sphere.rs:20-27 in f64 from the outward normal (the face normal, un-flipped: exact)
+                                                          [&] { return sphere_uv(h.front ? h.normal : -h.normal); });
+                        // emission (the path ends) or attenuation, one copy for all three; a Noise colour arrives below
+                        if (!TEXTURED || noise_tex < 0) T = T * tex;
+                    }
+                    RT_REGION(9); // texture, step 1
+                    // With four arms, what every material does with the hit goes before the switch: a value
+                    // assigned in one arm only costs every arm a copy where they meet (C2 -1.7 %; with the two
+                    // arms of the other variants the same hoist costs C3 1 %).  A light ends the path, the point
+                    // of a Noise light is read below; hit_normal and fuzz are Metal's, dead for the others.
+                    const d3 d_in = d;
+                    if (SPECULAR) {
+                        o = h.point;
+                        cand_base = 0;
+                        hit_normal = h.normal;
+                        fuzz = M.fuzz;
+                    }
+                    if (kind == RT_MAT_DIFFUSE_LIGHT) { // diffuse_light.rs:25-37
+                        ended = true;
+                        if (!SPECULAR && TEXTURED) o = h.point;
+                    } else if (!SPECULAR || kind == RT_MAT_LAMBERTIAN) { // lambertian.rs:26-38 (direction below)
+                        if (!SPECULAR) {
                             o = h.point;
                             cand_base = 0;
-                            hit_normal = h.normal;
-                            fuzz = M.fuzz;
                         }
-                        if (kind == RT_MAT_DIFFUSE_LIGHT) { // diffuse_light.rs:25-37
-                            ended = true;
-                            if (!SPECULAR && TEXTURED) o = h.point;
-                        } else if (!SPECULAR || kind == RT_MAT_LAMBERTIAN) { // lambertian.rs:26-38 (direction below)
-                            if (!SPECULAR) {
-                                o = h.point;
-                                cand_base = 0;
-                            }
-                            d = h.normal; // the incoming direction is dead: lambertian.rs:27 starts from the normal
-                            is_lambert = true;
-                            waiting = true;
-                        } else if (SPECULAR && kind == RT_MAT_METAL) { // metal.rs:26-43
-                            const d3 ud = unit_fast(d_in);
-                            d = ud - (2.0 * dot(ud, h.normal)) * h.normal; // metal.rs:30 reflect(); the fuzz term follows below
-                            is_lambert = false;
-                            waiting = fuzz != 0.0; // fuzz 0 multiplies the sample by 0: its draws are dead
-                            finish = !waiting;
-                        } else { // dialectric.rs:25-55
-                            const double ratio = h.front ? M.color[0] : M.ior; // 1 / ior, divided at upload
-                            const d3 ud = unit_fast(d_in);
-                            const double cos_theta = fmin(dot(-ud, h.normal), 1.0);
-                            const double sin_theta = sqrt_fast(1.0 - cos_theta * cos_theta);
-                            bool reflect_it = ratio * sin_theta > 1.0;
-                            if (!reflect_it) { // the draw happens only when refraction is possible
-                                const double r0 = h.front ? M.color[1] : M.color[2]; // ((1 - ratio) / (1 + ratio))^2, at upload
-                                const double m = 1.0 - cos_theta;
-                                const double m2 = m * m;
-                                const double refl = r0 + (1.0 - r0) * (m2 * m2 * m);
-                                const u4 b = rng.block(seg, RT_RNG_DIELECTRIC, 0);
-                                reflect_it = refl > u53(b.a, b.b);
-                            }
-                            if (reflect_it) {
-                                d = ud - (2.0 * dot(ud, h.normal)) * h.normal;
-                            } else { // vec3.rs:416-422
-                                const d3 perp = ratio * (ud + cos_theta * h.normal);
-                                d = perp + (-sqrt_fast(fabs(1.0 - len2(perp)))) * h.normal;
-                            }
-                            scattered = true;
+                        d = h.normal; // the incoming direction is dead: lambertian.rs:27 starts from the normal
+                        is_lambert = true;
+                        waiting = true;
+                    } else if (SPECULAR && kind == RT_MAT_METAL) { // metal.rs:26-43
+                        const d3 ud = unit_fast(d_in);
+                        d = ud - (2.0 * dot(ud, h.normal)) * h.normal; // metal.rs:30 reflect(); the fuzz term follows below
+                        is_lambert = false;
+                        waiting = fuzz != 0.0; // fuzz 0 multiplies the sample by 0: its draws are dead
+                        finish = !waiting;
+                    } else { // dialectric.rs:25-55
+                        const double ratio = h.front ? M.color[0] : M.ior; // 1 / ior, divided at upload
+                        const d3 ud = unit_fast(d_in);
+                        const double cos_theta = fmin(dot(-ud, h.normal), 1.0);
+                        const double sin_theta = sqrt_fast(1.0 - cos_theta * cos_theta);
+                        bool reflect_it = ratio * sin_theta > 1.0;
+                        if (!reflect_it) { // the draw happens only when refraction is possible
+                            const double r0 = h.front ? M.color[1] : M.color[2]; // ((1 - ratio) / (1 + ratio))^2, at upload
+                            const double m = 1.0 - cos_theta;
+                            const double m2 = m * m;
+                            const double refl = r0 + (1.0 - r0) * (m2 * m2 * m);
+                            const u4 b = rng.block(seg, RT_RNG_DIELECTRIC, 0);
+                            reflect_it = refl > u53(b.a, b.b);
                         }
-                    }
-                }
-            }
-
-            // ---- the wave evaluates the open rejection loops together (all 64 lanes arrive
-            // here).  A request still open afterwards resumes next iteration, which costs its lane
-            // one idle pass.  On cornell-like scenes (many requests, cheap iterations) two rounds
-            // settle ~90 % and a third costs more than the idle lanes it saves; where an iteration
-            // is expensive (textures, glass) or requests are few, up to four rounds pay: the loop
-            // stops as soon as nothing is pending (measured: C2 +1.4 %, C4 +2.7 %, C3 -9 % with 3).
-            RT_REGION(4); // miss / material
-            if constexpr (TEXTURED) { // the Noise lookups of this iteration, by the whole wave (all 64 lanes arrive here)
-                const bool lookup = noise_tex >= 0;
-                if (__ballot(lookup) != 0) {
-                    const Texture *tt = BVH ? A.textures : lds_textures;
-                    const double turb = coop_noise_turbulence(lookup, o, lookup ? tt[noise_tex].depth : 0,
-                                                              lookup ? tt[noise_tex].perlin : 0, A, lds_perlin, lane, L.scratch.noise);
-                    if (lookup) {
-                        const d3 tex = noise_colour(tt[noise_tex], o, turb);
-                        T = T * tex; // DiffuseLight's emission (the path has ended) or Lambertian / Metal attenuation
-                    }
-                }
-            }
-            RT_REGION(10); // Noise rounds
-            d3 sph = mk(0.0, 0.0, 0.0); // (left uninitialised, three moves fewer per iteration cost the plain variants 16 bytes of scratch)
-            if (coop_random_in_unit_sphere(waiting, rng.pixel, rng.sample, seg, cand_base, A.seed_lo, A.seed_hi, lane,
-                                           L.scratch.req, (TEXTURED || SPECULAR) ? 4 : 2, sph)) {
-                waiting = false;
-                finish = true;
-            }
-
-            RT_REGION(5); // sampler
-            if (finish) {
-                if (is_lambert) { // lambertian.rs:27-33
-                    const d3 dir = d + unit_fast(sph); // d holds the normal since the hit
-                    // vec3.rs:127-130 near_zero keeps the normal: once in 10^23 samples, so the wave branches
-                    // around the six selects it would otherwise issue every time
-                    const bool near_zero = fabs(dir.x) < 1e-8 && fabs(dir.y) < 1e-8 && fabs(dir.z) < 1e-8;
-                    const d3 normal = d;
-                    d = dir;
-                    if (__ballot(near_zero) != 0) {
-                        asm volatile("; near_zero (keeps the compiler from turning the branch back into selects)");
-                        if (near_zero) d = normal;
-                    }
-                    scattered = true;
-                } else if (SPECULAR) { // metal.rs:31-42: d holds the reflected direction since the hit
-                    if (fuzz != 0.0) d = d + fuzz * sph;
-                    if (dot(d, hit_normal) < 0.0) {
-                        T = mk(0.0, 0.0, 0.0);
-                        ended = true;
-                    } else {
+                        if (reflect_it) {
+                            d = ud - (2.0 * dot(ud, h.normal)) * h.normal;
+                        } else { // vec3.rs:416-422
+                            const d3 perp = ratio * (ud + cos_theta * h.normal);
+                            d = perp + (-sqrt_fast(fabs(1.0 - len2(perp)))) * h.normal;
+                        }
                         scattered = true;
                     }
                 }
             }
-            // renderer.rs:48-55: the recursion's next level has depth 0 -> white
-            if (scattered && (int)++seg >= A.max_depth) ended = true;
-            if (alive && ended) { // vec3.rs:38-42 Color::add into the pixel's sum
-                atomicAdd(&L.sum[pix][0], T.x);
-                atomicAdd(&L.sum[pix][1], T.y);
-                atomicAdd(&L.sum[pix][2], T.z);
-                alive = false;
-            }
-            RT_REGION(6); // scatter + accumulate
         }
 
-        RT_REGION(6); // scatter + accumulate (tail of the last iteration)
-        // ---- item done: its sums go to its own slice of `partial`
-        if (A.deliver_out == nullptr) {
-            if (my_valid) {
-                // slice row = row of the launch's owned-row grid (a share's slices hold its own rows only)
-                const size_t in_slice = (size_t)(ty * 8 + (lane >> 3)) * (size_t)A.width + (size_t)((tx * 8 + (lane & 7)) * A.step_x);
-                double *dst = A.partial + ((size_t)(A.chunk_base + (int)chunk) * (size_t)A.slice_rows * (size_t)A.width + in_slice) * 3;
-                dst[0] = L.sum[lane][0];
-                dst[1] = L.sum[lane][1];
-                dst[2] = L.sum[lane][2];
+        // ---- the wave evaluates the open rejection loops together (all 64 lanes arrive
+        // here).  A request still open afterwards resumes next iteration, which costs its lane
+        // one idle pass.  On cornell-like scenes (many requests, cheap iterations) two rounds
+        // settle ~90 % and a third costs more than the idle lanes it saves; where an iteration
+        // is expensive (textures, glass) or requests are few, up to four rounds pay: the loop
+        // stops as soon as nothing is pending (measured: C2 +1.4 %, C4 +2.7 %, C3 -9 % with 3).
+        RT_REGION(4); // miss / material
+        if constexpr (TEXTURED) { // the Noise lookups of this iteration, by the whole wave (all 64 lanes arrive here)
+            const bool lookup = noise_tex >= 0;
+            if (ballot(lookup) != 0) {
+                const Texture *tt = BVH ? A.textures : lds_textures;
+                const double turb = coop_noise_turbulence(lookup, o, lookup ? tt[noise_tex].depth : 0,
+                                                          lookup ? tt[noise_tex].perlin : 0, A, lds_perlin, lane, L.scratch.noise);
+                if (lookup) {
+                    const d3 tex = noise_colour(tt[noise_tex], o, turb);
+                    T = T * tex; // DiffuseLight's emission (the path has ended) or Lambertian / Metal attenuation
+                }
             }
-        } else {
-            deliver_item(kernargs_here(), L.sum[lane][0], L.sum[lane][1], L.sum[lane][2], my_valid, (int)chunk, tx, ty, tile_py0, rows_aligned, region, reg_tiles);
+        }
+        RT_REGION(10); // Noise rounds
+        d3 sph = mk(0.0, 0.0, 0.0); // (left uninitialised, three moves fewer per iteration cost the plain variants 16 bytes of scratch)
+        if (coop_random_in_unit_sphere(waiting, rng.pixel, rng.sample, seg, cand_base, A.seed_lo, A.seed_hi, lane,
+                                       L.scratch.req, (TEXTURED || SPECULAR) ? 4 : 2, sph)) {
+            waiting = false;
+            finish = true;
+        }
+
+        RT_REGION(5); // sampler
+        if (finish) {
+            if (is_lambert) { // lambertian.rs:27-33
+                const d3 dir = d + unit_fast(sph); // d holds the normal since the hit
+                // vec3.rs:127-130 near_zero keeps the normal: once in 10^23 samples, so the wave branches
+                // around the six selects it would otherwise issue every time
+                const bool near_zero = fabs(dir.x) < 1e-8 && fabs(dir.y) < 1e-8 && fabs(dir.z) < 1e-8;
+                const d3 normal = d;
+                d = dir;
+                if (ballot(near_zero) != 0) {
+                    asm volatile("; near_zero (keeps the compiler from turning the branch back into selects)");
+                    if (near_zero) d = normal;
+                }
+                scattered = true;
+            } else if (SPECULAR) { // metal.rs:31-42: d holds the reflected direction since the hit
+                if (fuzz != 0.0) d = d + fuzz * sph;
+                if (dot(d, hit_normal) < 0.0) {
+                    T = mk(0.0, 0.0, 0.0);
+                    ended = true;
+                } else {
+                    scattered = true;
+                }
+            }
+        }
+        // renderer.rs:48-55: the recursion's next level has depth 0 -> white
+        if (scattered && (int)++seg >= A.max_depth) ended = true;
+        if (alive && ended) { // vec3.rs:38-42 Color::add into the pixel's sum
+            // (the scale is a power of two: its upper half lives in ONE scalar register across the loop — a scalar load and its
+            // wait here, in every iteration, showed in the frame time)
+            if (FIXED_SUMS) {
+                const uint32_t scale_hi = sum_scale_hi;
+                // T * scale + 2^52 (one fma: the product is exact, the sum rounds T to a multiple of 1 / scale) has the
+                // integer in its mantissa; integer adds commute exactly (start_item has taken the exponent fields off)
+                const double scale = __longlong_as_double((long long)((unsigned long long)scale_hi << 32));
+                unsigned long long *sum = reinterpret_cast<unsigned long long *>(L.sum[spix]);
+                atomicAdd(sum + 0, (unsigned long long)__double_as_longlong(fma(T.x, scale, 0x1p52)));
+                atomicAdd(sum + 1, (unsigned long long)__double_as_longlong(fma(T.y, scale, 0x1p52)));
+                atomicAdd(sum + 2, (unsigned long long)__double_as_longlong(fma(T.z, scale, 0x1p52)));
+            } else {
+                atomicAdd(&L.sum[spix][0], T.x);
+                atomicAdd(&L.sum[spix][1], T.y);
+                atomicAdd(&L.sum[spix][2], T.z);
+            }
+            alive = false;
+        }
+        RT_REGION(6); // scatter + accumulate
+        // ---- ONE way out of the path loop, down here (a second `break`, or one inside an else-arm of the hand-out, had the
+        // compiler merge the lanes' alive / waiting / material masks under the exec mask at two more joins: +20 scalar
+        // instructions per iteration on a kernel whose scalar unit is busy 70 % of the time): an item event is due — the pool
+        // has run dry and the other slot is free to take what is in flight of it, or the draining item's last path has ended.
+        // ("Nothing in flight" is one of the two: a pool that is not dry feeds the lanes in the next iteration.)
+        if (OVERLAP) {
+            uint32_t st = state;
+            asm volatile("" : "+s"(st)); // (opaque: `state` does not change in this loop)
+            uint64_t go = ~0ull; // (a scalar 64-bit value, not a bool: see the flags above)
+            if ((st & DRAINING) != 0u) go = ballot(alive && (!OVERLAP || (((uint32_t)spix ^ st) & CUR) != 0u));
+            else if ((st & HAVE) != 0u && next >= total) go = 0ull;
+            if (go == 0ull) break;
+        }
         }
     }
-
     RT_REGION(7); // item end
     RT_REGION_FLUSH
     unsigned long long total_segments = n_segments; // one atomic per wave for the statistic
@@ -1071,13 +1244,21 @@ template <int PRIMS, bool TEXTURED, bool SPECULAR, bool BVH> struct PoolVariant 
         const size_t dyn = (BVH ? (size_t)a.bvh_lds_nodes * sizeof(rtdev::BvhNode)
                                 : (size_t)a.n_prims * sizeof(rtdev::Prim) + (TEXTURED ? (size_t)a.n_textures * sizeof(rtdev::Texture) : 0)) +
                            (TEXTURED && a.perlin_in_lds ? sizeof(double) * 256 * 3 : 0) +
-                           (a.lens_lds ? rtdev::pool_lens_lds_bytes(BVH) : 0);
+                           (a.lens_lds ? rtdev::pool_lens_lds_bytes(BVH) : 0) + (a.time_lds ? rtdev::pool_time_lds_bytes(BVH) : 0);
         hipLaunchKernelGGL((RT_KNS::k_trace_pool_f64<PRIMS, TEXTURED, SPECULAR, BVH>), dim3(blocks), dim3(256), dyn, stream, a);
     }
     static int blocks_per_cu(size_t dyn_lds) {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, RT_KNS::k_trace_pool_f64<PRIMS, TEXTURED, SPECULAR, BVH>, 256, dyn_lds) != hipSuccess)
             return 1;
+        // The calculator divides the CU's 160 KB by the block's LDS bytes; the hardware hands LDS out in granules of 1280
+        // bytes, 128 to a CU (tools/microbench/lds_fit.hip: 23 168 bytes per block already leave 6 blocks where the
+        // calculator says 7).  A persistent grid one block per CU too large runs that block when the others are done.
+        hipFuncAttributes attr;
+        if (hipFuncGetAttributes(&attr, (const void *)RT_KNS::k_trace_pool_f64<PRIMS, TEXTURED, SPECULAR, BVH>) == hipSuccess) {
+            const size_t granules = (attr.sharedSizeBytes + dyn_lds + 1279) / 1280;
+            if (granules > 0 && (int)(128 / granules) < n) n = (int)(128 / granules);
+        }
         return n < 1 ? 1 : n;
     }
 };

@@ -272,7 +272,15 @@ def test_v1_kernel_still_matches_the_oracle(rt, orc, gpu, scene_fn):
         d = np.abs(frames[name] - ref)
         assert d.max() < TOL and (d > TIGHT).mean() < 2e-3, name
         assert abs(int(segs) - ref_segs) <= 4
-    assert np.abs(frames["pool"] - frames["v1"]).max() < 1e-9
+    if scene_fn is not S.cornell_box_boxes:
+        assert np.abs(frames["pool"] - frames["v1"]).max() < 1e-9
+    else:
+        # The pooled variants that keep two items in flight (any primitive kind, BVH) add FIXED-POINT sums: an absolute
+        # quantum of E 2^-52 per sample (E = 16 bounds this scene's radiance; rt_device_types.h: sum_scale) where a double
+        # has a relative one.  In radiance — the square of what the frame holds — the two kernels agree to that quantum; a
+        # pixel that is black for every purpose may come out up to sqrt(E 2^-53) = 4e-8 apart.
+        assert np.abs(frames["pool"] ** 2 - frames["v1"] ** 2).max() < 1e-13  # (the quantum, 3.6e-15, and the order of the f64 sums)
+        assert np.abs(frames["pool"] - frames["v1"]).max() < 5e-8
 
 
 def test_tile_stream_refuses_strips(rt, gpu):
