@@ -306,6 +306,42 @@ __device__ __forceinline__ bool rect_t(int axis, double a0, double a1, double b0
     return !miss;
 }
 
+// The free-standing rect test of the linear loop, WRITTEN OUT (RT_ARITH_FAST): rect_t<true> above and the update of the
+// closest hit, `if (hit) { best_t = t; best = i; }`, instruction for instruction — the same subtraction, product, two fma
+// and six comparisons (so the same t, the same decisions, NaNs included) — but with the comparisons as v_cmpx, which
+// narrow the exec mask themselves.  As the compiler builds it every rect costs 8 scalar instructions (three s_and_b64 of
+// the comparison masks, two s_and_saveexec, two s_or exec, a branch) around its 12 vector ones, and the scalar unit — one
+// per CU, shared by its four SIMDs — is what the rects-only variant waits for once the vector pipes are full
+// (tools/bb_profile.py: 234 scalar instructions per iteration, 77 of them here).  This form has two, and the early out.
+template <int AXIS>
+__device__ __forceinline__ void rect_closest_update(double a0, double a1, double b0, double b1, double k, d3 o, d3 d, d3 inv_d,
+                                                    double t_min, double &best_t, int &best, int i) {
+    constexpr int IA = AXIS == 0 ? 1 : 0, IB = AXIS == 2 ? 1 : 2;
+    double t, a, b;
+    unsigned long long saved;
+    asm volatile("v_add_f64 %[t], %[k], -%[oc]\n\t"
+                 "v_mul_f64 %[t], %[inv], %[t]\n\t"          // xy_rect.rs:31 (k - o) / d with the ray's reciprocal
+                 "s_mov_b64 %[saved], exec\n\t"
+                 "v_cmpx_ngt_f64 %[tmin], %[t]\n\t"          // xy_rect.rs:32  not (t < t_min) ...
+                 "v_cmpx_ngt_f64 %[t], %[bt]\n\t"            //                ... and not (t > t_max)
+                 "s_cbranch_execz 1f\n\t"                    // no lane reaches the plane inside the range: the early out
+                 "v_fma_f64 %[a], %[da], %[t], %[oa]\n\t"    // xy_rect.rs:35-36
+                 "v_fma_f64 %[b], %[db], %[t], %[ob]\n\t"
+                 "v_cmpx_ngt_f64 %[a0], %[a]\n\t"            // xy_rect.rs:37  not (a < a0), not (a > a1), not (b < b0), not (b > b1)
+                 "v_cmpx_nlt_f64 %[a1], %[a]\n\t"
+                 "v_cmpx_ngt_f64 %[b0], %[b]\n\t"
+                 "v_cmpx_nlt_f64 %[b1], %[b]\n\t"
+                 "v_mov_b64 %[bt], %[t]\n\t"                 // the lanes still enabled have a closer hit
+                 "v_mov_b32 %[best], %[i]\n"
+                 "1:\n\t"
+                 "s_mov_b64 exec, %[saved]"
+                 : [t] "=&v"(t), [a] "=&v"(a), [b] "=&v"(b), [saved] "=&s"(saved), [bt] "+v"(best_t), [best] "+v"(best)
+                 : [k] "s"(k), [oc] "v"(comp(o, AXIS)), [inv] "v"(comp(inv_d, AXIS)), [tmin] "s"(t_min), [da] "v"(comp(d, IA)),
+                   [oa] "v"(comp(o, IA)), [db] "v"(comp(d, IB)), [ob] "v"(comp(o, IB)), [a0] "s"(a0), [a1] "s"(a1), [b0] "s"(b0),
+                   [b1] "s"(b1), [i] "s"(i)
+                 : "vcc");
+}
+
 // box.rs:22-71 side s of a Boxx: axis and (a0,a1,b0,b1,k)
 __device__ __forceinline__ void box_side(const double *p, int s, int &axis, double &a0, double &a1,
                                          double &b0, double &b1, double &k) {

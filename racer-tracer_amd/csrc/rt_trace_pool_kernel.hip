@@ -82,8 +82,9 @@
 #define RT_OCC_ANY 5 // untextured linear-loop variants with any primitive kind (cornell_box_boxes: 4 -> 5 waves per SIMD 20.7 -> 19.3 ms)
 #endif
 #ifndef RT_OCC_PLAIN
-#define RT_OCC_PLAIN 6 // rects-only / spheres-only, no textures, no specular materials: 80 VGPRs, six blocks per CU when LDS allows (the bound is what keeps
-                       // the allocator there: with 5 it drifts to 81-89 whenever the code around the path loop changes, and the sixth block is worth 4 %)
+#define RT_OCC_PLAIN 7 // rects-only / spheres-only, no textures, no specular materials: 72 VGPRs, seven blocks per CU when LDS allows (C3 73.4 ->
+                       // 72.0 ms against six).  Six needed 80 of the 79 the allocator wanted until the path state was re-set between
+                       // items (its live ranges then end at the path loop's exit: 73); the bound keeps the allocator there.
 #endif
 namespace RT_KNS {
 
@@ -921,6 +922,10 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                         // The table is grouped (rect_end, sphere_end): one straight-line test per group, the plane a
                         // compile-time constant, instead of a scalar switch on the kind of every record.
                         auto test_plane = [&](auto axis, const Prim &P, int i) {
+#ifndef RT_EXACT_DIV
+                            rect_closest_update<decltype(axis)::value>(P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, 0.001, best_t, best, i);
+                            return;
+#endif
                             double t;
                             if (rect_t<true>(decltype(axis)::value, P.p[0], P.p[1], P.p[2], P.p[3], P.p[4], o, d, inv_d, 0.001, best_t, t)) {
                                 best_t = t;
