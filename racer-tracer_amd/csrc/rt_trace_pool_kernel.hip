@@ -584,6 +584,9 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
     int smp0 = 0, n_valid = 0;
     int tile_py0 = 0; // image row of the current tile's first row; -1: strips that cut tiles (the batches then take the long road)
     uint32_t total = 0, next = 0, n_batches = 0, batches_done = 0;
+    // `next` at which the next batch of camera samples is due (batch b when next >= (b - (NBUF - 1)) * 64: NBUF batches stay
+    // ahead of the hand-out), or ~0 when the item's batches are all drawn: ONE scalar compare per iteration decides
+    uint32_t batch_due = ~0u;
     uint32_t my_pixel = 0; // image index of this lane's pixel of the current item's tile
 
     RT_REGION_DECL
@@ -683,6 +686,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
         next = 0;
         n_batches = (total + 63u) >> 6;
         batches_done = 0;
+        batch_due = n_batches > 0u ? 0u : ~0u;
         return true;
     };
     // The item of slot `s` has no path left: its sums go to its own slice of `partial` (or the launch finishes the tile's
@@ -748,6 +752,8 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
     // once — every lane busy — into LDS, two batches ahead of `next`.  (The buffers belong to the current item: an item
     // that still has paths in flight when the next one starts has handed out all its entries.)
     auto prepare_batch = [&](uint32_t b) {
+        int lane = lane_of_wave; // (opaque, like start_item's)
+        asm volatile("" : "+v"(lane));
         const RT_CONSTANT TraceArgs *K = kernargs_here();
         const uint32_t w = b * 64u + (uint32_t)lane;
         const bool in_pool = w < total;
@@ -793,6 +799,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
         if ((state & (HAVE | DRAINING)) == HAVE && next >= total) { // the pool is dry: what is in flight of it drains in the other slot
             state ^= HAVE | DRAINING | (OVERLAP ? CUR : 0u);
             total = next = n_batches = batches_done = 0; // (no pool: the hand-out below finds nothing to do)
+            batch_due = ~0u;
         }
         // (without OVERLAP there is one slot, and whatever is in flight belongs to the draining item)
         if ((state & DRAINING) != 0u && ballot(alive && (!OVERLAP || (((uint32_t)spix ^ state) & CUR) != 0u)) == 0) { // the last path of the draining item has ended
@@ -818,7 +825,10 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
         // ---- the path loop: until the pool runs dry or the draining item's last path ends
         for (;;) {
         // ---- camera samples for the entries about to leave the pool (whole wave, see above)
-        while (batches_done < n_batches && batches_done <= (next >> 6) + (uint32_t)(NBUF - 1)) prepare_batch(batches_done++);
+        while (next >= batch_due) {
+            prepare_batch(batches_done++);
+            batch_due = batches_done >= n_batches ? ~0u : (batches_done < (uint32_t)NBUF ? 0u : (batches_done - (uint32_t)(NBUF - 1)) << 6);
+        }
         RT_REGION(1); // batches
         // ---- hand pool entries to the lanes without a path (ballot + prefix count)
         if (next < total) {
@@ -932,53 +942,61 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                                 best = i;
                             }
                         };
-                        auto group = [&](auto axis, int begin, int end) {
-                            int i = begin;
-                            for (; i + 1 < end; i += 2) {
-                                const Prim pa = load_prim_uniform(A.prims, i), pb = load_prim_uniform(A.prims, i + 1);
+                        // ONE pointer runs through the groups (they follow each other in the table): an address formed from the
+                        // index — a 64-bit multiply-add, four scalar instructions — for every group's first record and every odd
+                        // one out was a tenth of the rects-only variant's scalar instructions
+                        const Prim *rec = A.prims;
+                        int i = 0;
+                        auto group = [&](auto axis, int end) {
+                            for (; i + 1 < end; i += 2, rec += 2) {
+                                const Prim pa = load_prim_uniform(rec, 0), pb = load_prim_uniform(rec, 1);
                                 test_plane(axis, pa, i);
                                 test_plane(axis, pb, i + 1);
                             }
-                            if (i < end) test_plane(axis, load_prim_uniform(A.prims, i), i);
+                            if (i < end) {
+                                test_plane(axis, load_prim_uniform(rec, 0), i);
+                                ++i;
+                                ++rec;
+                            }
                         };
                         // the group bounds are re-read from the kernel arguments HERE (kernargs_here): hoisted out of the
                         // path loop their emptiness tests sit in SGPR pairs that the allocator parks in VGPR lanes, and
                         // every iteration pays a v_readlane (4.3 SIMD cycles of the saturated vector pipe) per half of them
                         const RT_CONSTANT TraceArgs *KB = kernargs_here();
                         const int end_xy = KB->rect_end[0], end_xz = KB->rect_end[1], end_yz = KB->rect_end[2];
-                        group(std::integral_constant<int, 2>(), 0, end_xy);       // XY
-                        group(std::integral_constant<int, 1>(), end_xy, end_xz);  // XZ
-                        group(std::integral_constant<int, 0>(), end_xz, end_yz);  // YZ
+                        group(std::integral_constant<int, 2>(), end_xy);  // XY
+                        group(std::integral_constant<int, 1>(), end_xz);  // XZ
+                        group(std::integral_constant<int, 0>(), end_yz);  // YZ
                         if (PRIMS == PRIMS_ANY) {
-                            int i = end_yz;
-                            for (; i < A.sphere_end; ++i) { // plain spheres: sphere.rs:39-59, no switch, no wrapper
+                            for (; i < A.sphere_end; ++i, ++rec) { // plain spheres: sphere.rs:39-59, no switch, no wrapper
                                 double t;
                                 int aux;
-                                if (prim_t<PRIMS_SPHERES>(load_prim_uniform(A.prims, i), o, d, inv_d, inv_a, ray_time, 0.001, best_t, t, aux)) {
+                                if (prim_t<PRIMS_SPHERES>(load_prim_uniform(rec, 0), o, d, inv_d, inv_a, ray_time, 0.001, best_t, t, aux)) {
                                     best_t = t;
                                     best = i;
                                     best_aux = 0;
                                 }
                             }
-                            for (; i < KB->box_end; ++i) { // boxes, bare or wrapped: box.rs:82-101 as three slabs, no switch
+                            for (; i < KB->box_end; ++i, ++rec) { // boxes, bare or wrapped: box.rs:82-101 as three slabs, no switch
                                 double t;
                                 int side;
-                                if (box_t(load_prim_uniform(A.prims, i), o, d, inv_d, 0.001, best_t, t, side)) {
+                                if (box_t(load_prim_uniform(rec, 0), o, d, inv_d, 0.001, best_t, t, side)) {
                                     best_t = t;
                                     best = i;
                                     best_aux = side;
                                 }
                             }
-                            for (; i < A.n_prims; ++i) test(load_prim_uniform(A.prims, i), i); // moving spheres, wrapped rects and spheres
+                            for (; i < A.n_prims; ++i, ++rec) test(load_prim_uniform(rec, 0), i); // moving spheres, wrapped rects and spheres
                         }
                     } else {
+                        const Prim *rec = A.prims;
                         int i = 0;
-                        for (; i + 1 < A.n_prims; i += 2) {
-                            const Prim pa = load_prim_uniform(A.prims, i), pb = load_prim_uniform(A.prims, i + 1);
+                        for (; i + 1 < A.n_prims; i += 2, rec += 2) {
+                            const Prim pa = load_prim_uniform(rec, 0), pb = load_prim_uniform(rec, 1);
                             test(pa, i);
                             test(pb, i + 1);
                         }
-                        if (i < A.n_prims) test(load_prim_uniform(A.prims, i), i);
+                        if (i < A.n_prims) test(load_prim_uniform(rec, 0), i);
                     }
                 }
                 RT_REGION(3); // closest hit
