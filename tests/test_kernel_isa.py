@@ -66,9 +66,11 @@ def test_deliver_item_hands_slices_over_with_sc1_and_waitcnt(pool_kernel_asm):
 
 def test_no_scratch_in_the_plain_variants(pool_kernel_asm):
     """The variants BASELINE configs 2 and 3 run keep their path state in registers: no private segment, and the
-    register count that six (five with specular materials) waves per SIMD need."""
+    register count that SEVEN (five with specular materials) waves per SIMD need — 72: the path state is re-set between
+    items, so that it holds no register across the item code (rt_trace_pool_kernel.hip)."""
     text = "\n".join(pool_kernel_asm)
-    for variant, max_vgprs in (("Li0ELb0ELb0ELb0E", 80), ("Li1ELb0ELb0ELb0E", 80), ("Li0ELb0ELb1ELb0E", 96), ("Li1ELb0ELb1ELb0E", 96)):
+    for variant, max_vgprs in (("Li0ELb0ELb0ELb0E", 72), ("Li1ELb0ELb0ELb0E", 72), ("Li0ELb0ELb1ELb0E", 96), ("Li1ELb0ELb1ELb0E", 96),
+                               ("Li2ELb0ELb0ELb0E", 96)):
         m = re.search(r"\.amdhsa_kernel _ZN10rtdev_fast16k_trace_pool_f64I" + variant + r".*?\.end_amdhsa_kernel", text, re.S)
         assert m, variant
         vgprs = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(0)).group(1))
@@ -90,3 +92,34 @@ def test_bvh_walk_reads_its_nodes_from_lds_not_through_flat_addresses(pool_kerne
         assert len(steps) == 6, (variant, len(steps))                     # three per step, two instantiations
         assert re.search(r"ds_read_b128[^\n]*\n(?:[^\n]*\n){0,12}?[^\n]*v_pk_fma_f32", body), variant
         assert re.search(r"global_load_dwordx4[^\n]*\n(?:[^\n]*\n){0,12}?[^\n]*v_pk_fma_f32", body), variant
+
+
+def kernel_body(text, variant):
+    start = text.index("\n_ZN10rtdev_fast16k_trace_pool_f64I" + variant)
+    return text[start:text.index(".Lfunc_end", start)]
+
+
+def test_rect_test_narrows_exec_itself(pool_kernel_asm):
+    """The free-standing rect test of the linear loop is written out with v_cmpx (rt_trace_common.h: rect_closest_update):
+    six comparisons that narrow the exec mask themselves, between ONE save and ONE restore of it — the compiler's form
+    ANDs four comparison masks in the scalar unit and saves / restores exec twice per rect (8 scalar instructions; the
+    scalar unit is what the rects-only variant waits for: C3 72.3 -> 69.5 ms)."""
+    text = "\n".join(pool_kernel_asm)
+    for variant in ("Li0ELb0ELb0ELb0E", "Li2ELb0ELb0ELb0E"):
+        body = kernel_body(text, variant)
+        blocks = re.findall(r";;#ASMSTART\n(.*?);;#ASMEND", body, re.S)
+        rects = [b for b in blocks if "v_cmpx_ngt_f64" in b]
+        assert len(rects) >= 9, (variant, len(rects))     # three planes x (two records of a pair + the odd one out)
+        for b in rects:
+            ops = [l.split()[0] for l in b.strip().split("\n") if l.strip() and not l.strip().endswith(":")]
+            assert ops.count("v_cmpx_ngt_f64") + ops.count("v_cmpx_nlt_f64") == 6, ops
+            assert [o for o in ops if o.startswith("s_")] == ["s_mov_b64", "s_cbranch_execz", "s_mov_b64"], ops
+
+
+def test_the_two_item_variants_add_integers_the_others_doubles(pool_kernel_asm):
+    """Per-pixel sums in LDS: ds_add_u64 (fixed point, order-independent) in the variants that keep two items in flight
+    (any primitive kind, BVH), ds_add_f64 in the rects-only / spheres-only ones — and never both in one kernel."""
+    text = "\n".join(pool_kernel_asm)
+    for variant, fixed in (("Li0ELb0ELb0ELb0E", False), ("Li1ELb1ELb1ELb0E", False), ("Li2ELb0ELb0ELb0E", True), ("Li2ELb1ELb1ELb1E", True)):
+        body = kernel_body(text, variant)
+        assert ("ds_add_u64" in body) == fixed and ("ds_add_f64" in body) == (not fixed), variant
