@@ -10,7 +10,8 @@ rt = importlib.import_module("racer-tracer_amd"); host = importlib.import_module
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 random.seed(3)
 for wl, cfg, scene, spp in (("c2", "config_c2.yml", "three_balls.yml", 48), ("c3", "config_c3.yml", "cornell_box.yml", 96),
-                            ("c4", "config_c4.yml", "noise_and_textures.yml", 32), ("random", "config_c2.yml", "random", 8)):
+                            ("c4", "config_c4.yml", "noise_and_textures.yml", 32), ("random", "config_c2.yml", "random", 8),
+                            ("boxes", "config_c3.yml", "cornell_box_boxes.yml", 32)):  # (random, boxes: two items in flight per wave)
     path = scene if scene == "random" else os.path.join(ROOT, "scenes", scene)
     s = host.Session(os.path.join(ROOT, "scenes", cfg), scene=path)
     p = s.params
