@@ -579,7 +579,8 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
     // ---- the item entries are handed out of (slot `cur` of L.sum / L.info); the other slot may hold an item whose
     // pool is dry and whose last paths are still in flight (`draining`)
     // HAVE: slot `cur` holds an item (its pool may be dry); CUR: cur << 6, the slot bit as it sits in a lane's `spix`
-    enum : uint32_t { HAVE = 1u, DRAINING = 2u, QUEUE_DRY = 4u, CUR = 64u };
+    // POOL_DRY (two-item variants): the hand-out has just taken the pool's last entries
+    enum : uint32_t { HAVE = 1u, DRAINING = 2u, QUEUE_DRY = 4u, POOL_DRY = 8u, CUR = 64u };
     uint32_t state = 0u;
     int smp0 = 0, n_valid = 0;
     int tile_py0 = 0; // image row of the current tile's first row; -1: strips that cut tiles (the batches then take the long road)
@@ -798,6 +799,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
         // per segment)
         if ((state & (HAVE | DRAINING)) == HAVE && next >= total) { // the pool is dry: what is in flight of it drains in the other slot
             state ^= HAVE | DRAINING | (OVERLAP ? CUR : 0u);
+            state &= ~POOL_DRY;
             total = next = n_batches = batches_done = 0; // (no pool: the hand-out below finds nothing to do)
             batch_due = ~0u;
         }
@@ -806,7 +808,10 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
             finish_item(OVERLAP ? (int)((state ^ CUR) >> 6) & 1 : 0);
             state &= ~DRAINING;
         }
-        if ((state & (HAVE | QUEUE_DRY)) == 0u && (FIXED_SUMS || (state & DRAINING) == 0u)) state |= start_item() ? HAVE : QUEUE_DRY;
+        if ((state & (HAVE | QUEUE_DRY)) == 0u && (FIXED_SUMS || (state & DRAINING) == 0u)) {
+            state |= start_item() ? HAVE : QUEUE_DRY;
+            if (OVERLAP && (state & HAVE) != 0u && total == 0u) state |= POOL_DRY; // (an item without a pixel: nothing to hand out)
+        }
         if ((state & (HAVE | DRAINING)) == 0u) break; // the queue is dry and nothing is in flight
         RT_REGION(0); // item setup / end
         if (!OVERLAP) {
@@ -837,6 +842,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
             // entries whose camera samples are in LDS: all of them with two buffers, the current batch with one
             const uint32_t ready = NBUF == 2 ? total : min(total, batches_done << 6);
             next = min(next + (uint32_t)__popcll(idle), ready);
+            if (OVERLAP && next >= total) state |= POOL_DRY;
             // entry_of(w) without the pixel arithmetic: lane p of the wave holds pixel p's index in the image
             // (my_pixel), so the entry's comes by a lane shuffle — which every lane has to take part in, hence
             // out here (the lanes that have a path compute an entry nobody reads)
@@ -1173,10 +1179,11 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
         if (OVERLAP) {
             uint32_t st = state;
             asm volatile("" : "+s"(st)); // (opaque: `state` does not change in this loop)
-            uint64_t go = ~0ull; // (a scalar 64-bit value, not a bool: see the flags above)
-            if ((st & DRAINING) != 0u) go = ballot(alive && (!OVERLAP || (((uint32_t)spix ^ st) & CUR) != 0u));
-            else if ((st & HAVE) != 0u && next >= total) go = 0ull;
-            if (go == 0ull) break;
+            if ((st & (DRAINING | POOL_DRY)) != 0u) { // (one scalar test in the usual iteration)
+                uint64_t go = 0ull; // (a scalar 64-bit value, not a bool: see the flags above)
+                if ((st & DRAINING) != 0u) go = ballot(alive && (((uint32_t)spix ^ st) & CUR) != 0u);
+                if (go == 0ull) break;
+            }
         }
         }
     }
