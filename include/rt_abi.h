@@ -269,6 +269,11 @@ enum RtTraceKernel {
  *     <= 1 ulp, FMA contraction on.  Against the reference's arithmetic (the oracle) the shipped scenes agree to
  *     ~1e-13 per channel; a scene that amplifies rounding (thousands of small mirrors: a bounce multiplies a
  *     direction error by distance / radius) can flip the odd hit, i.e. a few pixels in ten thousand beyond 1e-3.
+ *     Scenes with boxes, wrappers, moving spheres or more than 48 primitives add their per-pixel sums in 64-bit fixed
+ *     point (quantum: the scene's largest emission / background component x 2^-52 per sample — a pixel whose radiance
+ *     is of that order, black for every purpose, comes out up to 4e-8 from the f64 sum's value), which makes the frame
+ *     independent of how the GPU schedules the work; that needs a bound on a sample's radiance, so a scene with a
+ *     colour above 1 (or below 0, or not finite) on a scattering material is rendered as RT_ARITH_REFERENCE.
  *   RT_ARITH_REFERENCE: the reference's own operations (IEEE divisions, sqrt + three divisions, no contraction);
  *     holds the 1e-3 per-channel tolerance on such scenes too; ~25 % slower.  Same kernels, same draws, same
  *     closest-hit rule: only the last bits of the arithmetic differ. */
