@@ -215,7 +215,9 @@ def valu_roofline(c, kernel_ms, segments):
                  of the launch at the peak clock: the share of the launch in which the vector pipes were provably
                  occupied.  Both are <= 1 by construction.
     valu_busy  = 4 x SQ_ACTIVE_INST_VALU / SIMD-cycles: the hardware's own busy figure; it books a quad-cycle per
-                 instruction although 32-bit ones issue in 2, so it can pass 1 (round 2 printed it as `frac`)."""
+                 instruction although 32-bit ones issue in 2, so it can pass 1 (round 2 printed it as `frac`).
+    scalar_busy = SQ_ACTIVE_INST_SCA / CU-cycles: a CU has ONE scalar ALU for its four SIMDs; C3 kept it 67 % busy beside
+                 vector pipes at 98 % in round 3, and taking scalar instructions out is what moved the frame in round 4."""
     secs = kernel_ms * 1e-3
     simd_cycles = SIMDS * CLOCK_GHZ * 1e9 * secs
     total = c["SQ_INSTS_VALU"]["mean"]
@@ -224,6 +226,10 @@ def valu_roofline(c, kernel_ms, segments):
            "lanes_per_inst": round(lanes, 1),
            "valu_insts_per_launch": total,
            "valu_insts_per_segment": round(total / segments, 3)}
+    if mean_of(c, "SQ_ACTIVE_INST_SCA") is not None:
+        out["scalar_busy"] = round(c["SQ_ACTIVE_INST_SCA"]["mean"] / (simd_cycles / 4.0), 4)
+        if mean_of(c, "SQ_INSTS_SALU") is not None:
+            out["salu_insts_per_segment"] = round(c["SQ_INSTS_SALU"]["mean"] / segments, 3)
     if mean_of(c, "SQ_WAVE_CYCLES") and mean_of(c, "SQ_WAIT_INST_ANY") is not None:
         out["wave_time_waiting_frac"] = round(c["SQ_WAIT_INST_ANY"]["mean"] / c["SQ_WAVE_CYCLES"]["mean"], 4)
         if mean_of(c, "SQ_ACTIVE_INST_ANY") is not None:

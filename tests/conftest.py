@@ -29,6 +29,12 @@ def rt():
 
 
 @pytest.fixture(scope="session")
+def host():
+    """The ctypes binding of the C++ host layer (include/rt_host.h)."""
+    return importlib.import_module("racer-tracer_amd.host")
+
+
+@pytest.fixture(scope="session")
 def abi():
     return importlib.import_module("racer-tracer_amd.abi")
 

@@ -114,3 +114,31 @@ def test_chunks_longer_than_2048_samples_halve_the_scale(rt, gpu):
             scene.close()
     assert np.abs(frames[0] ** 2 - frames[1] ** 2).max() < 1e-10
     assert np.abs(frames[0] - frames[1]).max() < 1e-7
+
+
+def test_bvh_variant_frames_do_not_depend_on_strips_that_cut_tiles(rt, host, gpu):
+    """The same for the BVH variant (485 spheres, moving ones among them: ray times in dynamic LDS, lens samples, one batch
+    buffer): strips of 5 and 3 rows against the whole frame, bit for bit."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    session = host.Session(os.path.join(root, "scenes", "config_c2.yml"), scene="random")
+    p = session.params
+    w, h, spp = 160, 88, 6
+    camera = host.camera_new((0, 2, 10), (0, 0, 0), 20.0, 0.1, 10.0, w, h)
+    scene = rt.Scene(session)
+    try:
+        def frame(**strip):
+            q = S.abi.render_params(w, h, spp, **strip)
+            q.max_depth, q.seed = p.max_depth, p.seed
+            return scene.render_frame(camera, q)
+        whole = frame()
+        assert np.isfinite(whole).all() and whole.max() > 0.1
+        for rows, count in ((5, 3), (3, 4), (8, 2)):
+            got = np.zeros_like(whole)
+            for index in range(count):
+                part = frame(strip_rows=rows, strip_count=count, strip_index=index)
+                own = ((np.arange(h) // rows) % count) == index
+                got[own] = part[own]
+            assert np.array_equal(got, whole), (rows, count)
+    finally:
+        scene.close()

@@ -108,6 +108,7 @@ def test_rect_test_narrows_exec_itself(pool_kernel_asm):
     for variant in ("Li0ELb0ELb0ELb0E", "Li2ELb0ELb0ELb0E"):
         body = kernel_body(text, variant)
         blocks = re.findall(r";;#ASMSTART\n(.*?);;#ASMEND", body, re.S)
+        assert "_dpp" not in body and "quad_perm" not in body   # (a DPP op within five instructions of a v_cmpx would need wait states)
         rects = [b for b in blocks if "v_cmpx_ngt_f64" in b]
         assert len(rects) >= 9, (variant, len(rects))     # three planes x (two records of a pair + the odd one out)
         for b in rects:
