@@ -59,9 +59,10 @@
 //    start the NEXT item's paths; per-pixel sums are 64-bit fixed-point integers, so the order in which samples arrive —
 //    which now depends on what else the wave traces — cannot change a bit of the frame (SUMS AND OVERLAPPED ITEMS below).
 //
-// The launch is VALU-throughput bound (DESIGN.md 4.2 / 6 and LABNOTES.md have the counters, the per-region
-// cycle profile of the -DRT_PROFILE_REGIONS build, and the variants that were measured and
-// dropped).
+// The launch is VALU-throughput bound with the CU's one scalar ALU close behind (scalar_busy 0.60 on C3: count scalar
+// instructions before vector ones; DESIGN.md 4.2 / 6 and LABNOTES.md have the counters, the per-region cycle profile of the
+// -DRT_PROFILE_REGIONS build — which adds 1.8 KB of LDS per block and can cost a variant at a granule edge a block per CU —
+// and the variants that were measured and dropped).
 #include <cstddef>
 #include <type_traits>
 #include "rt_trace_common.h"
