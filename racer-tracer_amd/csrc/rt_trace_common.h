@@ -251,7 +251,13 @@ struct Hit {
 
 __device__ __forceinline__ void set_face_normal(Hit &h, d3 dir, d3 outward) { // geometry.rs:49-56
     h.front = dot(dir, outward) < 0.0;
-    h.normal = h.front ? outward : -outward;
+    // `front ? outward : -outward` as ONE select of a sign mask and three xors of the upper halves (negation is the sign
+    // bit, whatever the value): four vector instructions where three negate-and-select pairs are six
+    const uint32_t flip = h.front ? 0u : 0x80000000u;
+    auto with_sign = [flip](double x) {
+        return __longlong_as_double((long long)((unsigned long long)__double_as_longlong(x) ^ ((unsigned long long)flip << 32)));
+    };
+    h.normal = mk(with_sign(outward.x), with_sign(outward.y), with_sign(outward.z));
 }
 
 // The same for the rects' outward normal +e_axis (xy_rect.rs:43-45 and its siblings): dot(dir, e_axis) is
