@@ -142,3 +142,31 @@ def test_bvh_variant_frames_do_not_depend_on_strips_that_cut_tiles(rt, host, gpu
             assert np.array_equal(got, whole), (rows, count)
     finally:
         scene.close()
+
+
+def test_default_scene_at_full_size_on_bands(rt, host, orc, gpu):
+    """The reference's default content (the Cornell box WITH its two rotated boxes, scene/sandbox.rs:39-80) at 1920x1080 x
+    128 spp through the two-item variant, against the oracle on three bands of rows: the fixed-point sums at the size and
+    sample count that are benchmarked.  In radiance the frames agree to the quantum and the arithmetic's own difference."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = host.Session(os.path.join(root, "scenes", "config_c3.yml"), scene=os.path.join(root, "scenes", "cornell_box_boxes.yml"))
+    p = s.params
+    p.samples = 128
+    assert (p.width, p.height, p.max_depth) == (1920, 1080, 20)
+    scene = rt.Scene(s)
+    try:
+        got = scene.render_frame(s.camera, p)
+        assert scene.last_stats().samples == 1920 * 1080 * 128
+    finally:
+        scene.close()
+    p.strip_rows, p.strip_count, p.strip_index = 2, 180, 100    # rows 200-201, 560-561, 920-921
+    # (the oracle's linear scan: through its BVH it replicates RotateY::create_bounding_box's arithmetic slip
+    # (rotate_y.rs:77,83-84), which culls rays that do hit the rotated boxes — 169 of these 11 520 pixels; SURVEY App. B-14)
+    ref, _ = orc.render(s.desc, s.camera, p, use_bvh=0)
+    rows = ((np.arange(p.height) // 2) % 180) == 100
+    d = np.abs(ref[rows] - got[rows])
+    assert d.max() < TOL
+    assert np.abs(ref[rows] ** 2 - got[rows] ** 2).max() < 1e-9                 # radiance
+    assert float((d.max(axis=-1) > 1e-9).mean()) < 2e-3                          # and almost everywhere in the frame's own terms
+    assert got[rows].std() > 0.05
