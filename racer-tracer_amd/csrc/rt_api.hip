@@ -270,7 +270,9 @@ void fill_args(const RtScene *s, const RtCamera *c, const RtRenderParams *p, rtd
     // (or the scale halves), stay below 2^63.
     if (!s->exact && !s->use_v1 && s->radiance_bound > 0.0) {
         int e = 0;
-        (void)frexp(s->radiance_bound, &e); // radiance_bound < 2^e
+        // radiance_bound < 2^e, with room for the last bits a sample may exceed the bound by (a sky blend or a Noise factor
+        // an ulp above 1, twenty bounces deep): a bound within 1e-6 of the power of two takes the next one
+        if (frexp(s->radiance_bound, &e) > 1.0 - 1e-6) ++e;
         const std::vector<int> plan = chunk_plan(p->samples);
         int longest = 1;
         for (size_t k = 0; k + 1 < plan.size(); ++k) longest = std::max(longest, plan[k + 1] - plan[k]);

@@ -771,8 +771,8 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
         if (K->cam.lens_radius != 0.0) {
             double lx = 0.0, ly = 0.0;
             coop_random_in_unit_disk(in_pool, pixel_b, sample_b, A.seed_lo, A.seed_hi, lane, L.scratch.req, lx, ly);
-            lens[buf][lane][0] = lx;
-            lens[buf][lane][1] = ly;
+            lens[buf][lane][0] = lx * K->cam.lens_radius; // camera.rs:327 `lens_radius * random_in_unit_disk()`: formed here, by all
+            lens[buf][lane][1] = ly * K->cam.lens_radius; // 64 lanes, not at the hand-out by the quarter of them that start a path
         }
     };
 
@@ -869,7 +869,7 @@ __global__ __launch_bounds__(256, TEXTURED ? (PRIMS == PRIMS_ANY ? (BVH ? RT_OCC
                 else d = ld3(L.base[pix_new]) - v * ld3(K->cam.vertical) - co;
                 const double lr = K->cam.lens_radius;
                 if (lr != 0.0) {
-                    const d3 offset = ld3(K->cam.right) * (lens[buf][slot][0] * lr) + ld3(K->cam.up) * (lens[buf][slot][1] * lr);
+                    const d3 offset = ld3(K->cam.right) * lens[buf][slot][0] + ld3(K->cam.up) * lens[buf][slot][1];
                     o = co + offset;
                     d = d - offset;
                 }
