@@ -170,3 +170,33 @@ def test_default_scene_at_full_size_on_bands(rt, host, orc, gpu):
     assert np.abs(ref[rows] ** 2 - got[rows] ** 2).max() < 1e-9                 # radiance
     assert float((d.max(axis=-1) > 1e-9).mean()) < 2e-3                          # and almost everywhere in the frame's own terms
     assert got[rows].std() > 0.05
+
+
+def with_light(bundle, emission):
+    textures = list(bundle.textures)
+    textures[3] = S.abi.solid((emission, emission, emission))
+    return S.abi.SceneBundle(list(bundle.primitives), list(bundle.materials), textures, S.abi.solid_background((0.0, 0.0, 0.0)))
+
+
+@pytest.mark.parametrize("emission", [16.0, 15.99999999, 1.0, 1e13])
+def test_radiance_bounds_at_the_edges(rt, gpu, emission):
+    """The scale of the fixed-point sums comes from the scene's largest emission: a bound that IS a power of two, one a hair
+    below it (the exponent keeps a margin), the smallest one (1: the white of an exhausted depth), and one beyond 2^40 —
+    where the scene takes the f64 sums of the reference copy.  Against that copy the radiance agrees to the quantum."""
+    bundle, cam, _ = S.cornell_box_boxes()
+    lit = with_light(bundle, emission)
+    w, h, spp = 96, 54, 16
+    camera = S.camera_for(cam, w, h)
+    params = S.abi.render_params(w, h, spp)
+    frames = []
+    for arithmetic in (S.abi.RT_ARITH_FAST, S.abi.RT_ARITH_REFERENCE):
+        scene = rt.Scene(lit, arithmetic=arithmetic)
+        try:
+            frames.append(scene.render_frame(camera, params))
+        finally:
+            scene.close()
+    assert np.isfinite(frames[0]).all() and frames[0].max() > 0.0
+    if emission > 2.0 ** 40:
+        assert np.array_equal(frames[0], frames[1])
+    else:
+        assert np.abs(frames[0] ** 2 - frames[1] ** 2).max() < 1e-11 * max(1.0, emission)
