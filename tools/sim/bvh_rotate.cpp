@@ -45,15 +45,18 @@ struct Tree {
         for (; i >= 0; i = n[i].parent)
             if (!n[i].leaf()) unite(n[n[i].l], n[n[i].r], n[i].mn, n[i].mx);
     }
-    double sah(double c_box = 1.0, double c_prim = 2.0) const { // expected cost per ray that hits the root, in box tests
+    // expected cost, in box tests, per ray that hits the box of node `top` (the whole tree by default; the ground sphere of
+    // the random scene makes the root's box a thousand times the field's, so the field's subtree is reported on its own)
+    double sah(int top = -1, double c_box = 1.0, double c_prim = 2.0) const {
+        if (top < 0) top = root;
         double cost = 0;
         std::function<void(int)> go = [&](int i) {
             cost += c_box * area(n[i]);
             if (n[i].leaf()) cost += c_prim * area(n[i]) * (double)n[i].prims.size();
             else { go(n[i].l); go(n[i].r); }
         };
-        go(root);
-        return cost / area(n[root]);
+        go(top);
+        return cost / area(n[top]);
     }
 };
 
@@ -277,7 +280,10 @@ int main(int argc, char **argv) {
         int best;
         for (const Ray &r : primary) walk(T, d, r, cp, best);
         for (const Ray &r : bounce) walk(T, d, r, cb, best);
-        printf("%-44s SAH cost %7.2f | primary rays: %5.2f boxes, %4.2f primitives | bounce rays: %5.2f boxes, %4.2f primitives\n", what, T.sah(),
+        int field = T.root; // the subtree without the dominating primitive: descend while one child is a single leaf
+        while (!T.n[field].leaf() && (T.n[T.n[field].l].leaf() || T.n[T.n[field].r].leaf()) && area(T.n[field]) > 1e5)
+            field = T.n[T.n[field].l].leaf() ? T.n[field].r : T.n[field].l;
+        printf("%-44s SAH cost %7.2f (the field's subtree: %6.2f) | primary rays: %5.2f boxes, %4.2f primitives | bounce rays: %5.2f boxes, %4.2f primitives\n", what, T.sah(), T.sah(field),
                (double)cp.boxes / cp.rays, (double)cp.prims / cp.rays, (double)cb.boxes / cb.rays, (double)cb.prims / cb.rays);
     };
     printf("random scene, %d primitives, %d nodes, <= %d primitives per leaf; %zu primary and %zu bounce rays\n", d->n_primitives, n, max_leaf,
