@@ -433,6 +433,19 @@ int rtapi::enqueue_render(RtScene *s, const RtCamera *camera, const RtRenderPara
         RT_HIP(hipMemsetAsync(s->segments.ptr + rtdev::RT_STAT_WALL + 2, 0xff, sizeof(unsigned long long), stream));
 #endif
         RT_HIP(hipMemsetAsync(s->queue.ptr, 0, sizeof(unsigned int) * s->queue.count, stream));
+        // A tree that lives in LDS is walked in ONE fixed child order: the order that suits the rays starting at this
+        // camera (rt_bvh.h: order_bvh_for_origin).  Re-emitted when the camera has moved — microseconds for the few hundred
+        // nodes LDS holds — and copied in stream order, i.e. behind whatever launch of this scene still walks the old array.
+        if (s->use_bvh && s->bvh_nodes_in_lds && !s->bvh_host.nodes.empty() &&
+            (!s->bvh_is_ordered || camera->origin[0] != s->bvh_ordered_for[0] || camera->origin[1] != s->bvh_ordered_for[1] ||
+             camera->origin[2] != s->bvh_ordered_for[2])) {
+            s->bvh_upload_slot ^= 1; // (two host copies in turn: the one a pending copy may still read is left alone)
+            std::vector<rtdev::BvhNode> &arr = s->bvh_ordered_nodes[s->bvh_upload_slot];
+            arr = rtdev::order_bvh_for_origin(s->bvh_host, camera->origin);
+            RT_HIP(hipMemcpyAsync(s->bvh_nodes.ptr, arr.data(), arr.size() * sizeof(rtdev::BvhNode), hipMemcpyHostToDevice, stream));
+            for (int k = 0; k < 3; ++k) s->bvh_ordered_for[k] = camera->origin[k];
+            s->bvh_is_ordered = true;
+        }
         RT_HIP(hipEventRecord(s->ev_begin, stream));
         // a slice is only written for the pixels a launch covers; unowned rows are skipped by the resolve
         int chunks_done = 0;
@@ -974,6 +987,10 @@ int scene_create(const RtSceneDesc *d, int device, const RtSceneOptions *options
             }
         }
         if ((rc = upload(s->bvh_nodes, bvh.nodes)) != RT_OK) return rc;
+        if (bvh.nodes.size() * sizeof(rtdev::BvhNode) <= 32 * 1024) { // the nodes live in LDS: kept for the per-camera child order (enqueue_render)
+            s->bvh_host.nodes = bvh.nodes;
+            for (int k = 0; k < 3; ++k) s->bvh_host.center[k] = bvh.center[k];
+        }
         if ((rc = upload(s->bvh_prim_index, bvh.prim_index)) != RT_OK) return rc;
         s->n_bvh_nodes = (int)bvh.nodes.size() - 1; // the array ends with the sentinel (rt_device_types.h: BvhNode)
         for (int k = 0; k < 3; ++k) {

@@ -279,4 +279,48 @@ BvhBuild build_bvh(const RtPrimitive *prims, int n_prims, int max_leaf, bool ord
     return out;
 }
 
+std::vector<BvhNode> order_bvh_for_origin(const BvhBuild &b, const double origin[3]) {
+    const size_t n = b.nodes.empty() ? 0 : b.nodes.size() - 1; // without the sentinel
+    std::vector<BvhNode> arr(b.nodes.size());
+    if (n == 0) return b.nodes;
+    auto dist2 = [&](const BvhNode &q) { // squared distance from the origin to the (f32, centre-relative) box; 0 inside
+        double s = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            const double o = origin[k] - b.center[k], lo = q.mn(k), hi = q.mx(k);
+            const double d = o < lo ? lo - o : (o > hi ? o - hi : 0.0);
+            s += d * d;
+        }
+        return s;
+    };
+    size_t next = 0;
+    struct Frame { int32_t node; int32_t emitted_at; int stage; };
+    std::vector<Frame> stack;
+    stack.push_back(Frame{0, -1, 0});
+    while (!stack.empty()) { // depth-first emission, as for the direction-ordered copies of build_bvh
+        Frame &f = stack.back();
+        const BvhNode &nd = b.nodes[(size_t)f.node];
+        if (f.stage == 0) {
+            f.emitted_at = (int32_t)next;
+            arr[next] = nd;
+            ++next;
+            if (nd.first_count != 0) { // leaf
+                arr[(size_t)f.emitted_at].skip = (int32_t)next;
+                stack.pop_back();
+                continue;
+            }
+            f.stage = 1;
+            const int32_t first_child = f.node + 1, second_child = b.nodes[(size_t)first_child].skip;
+            const bool flip = dist2(b.nodes[(size_t)second_child]) < dist2(b.nodes[(size_t)first_child]);
+            const int32_t first = flip ? second_child : first_child, second = flip ? first_child : second_child;
+            stack.push_back(Frame{second, -1, 0}); // (pushed first, so that `first` is emitted next)
+            stack.push_back(Frame{first, -1, 0});
+        } else {
+            arr[(size_t)f.emitted_at].skip = (int32_t)next;
+            stack.pop_back();
+        }
+    }
+    arr[n] = b.nodes.back(); // the sentinel
+    return arr;
+}
+
 } // namespace rtdev

@@ -34,6 +34,11 @@ struct BvhBuild {
 
 // Host-side build over the ABI primitives (wrappers and motion included in the bounds).
 BvhBuild build_bvh(const RtPrimitive *prims, int n_prims, int max_leaf = 4, bool ordered = false); // max_leaf: primitives per leaf, 1..7; ordered: also the eight direction-ordered arrays
+// The node array (sentinel included) with every inner node's children in the order of their boxes' distance from
+// `origin`, nearest first — the order a fixed-order walk wants for rays that START there: all primary rays of a camera.
+// Same nodes, boxes and leaves as b.nodes; only the order and the skip links differ (tools/sim/bvh_rotate.cpp: the
+// `random` scene's primary rays touch 28.1 boxes and 4.6 leaf primitives instead of 32.8 and 6.3; bounce rays the same).
+std::vector<BvhNode> order_bvh_for_origin(const BvhBuild &b, const double origin[3]);
 // True bounds of one primitive incl. RotateY / Translate / motion.
 void primitive_bounds(const RtPrimitive &p, double mn[3], double mx[3]);
 

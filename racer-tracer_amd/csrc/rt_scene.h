@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include "rt_device_types.h"
+#include "rt_bvh.h"
 #include "../../include/rt_abi.h"
 
 namespace rtapi {
@@ -91,6 +92,13 @@ struct RtScene {
     int n_bvh_nodes = 0;
     double bvh_root_mn[3] = {0, 0, 0}, bvh_root_mx[3] = {0, 0, 0}, bvh_center[3] = {0, 0, 0};
     bool bvh_nodes_in_lds = false; // node array (32 B each) staged in dynamic LDS when <= 32 KiB
+    // the tree on the host, for trees that live in LDS: before a launch the node array is re-emitted with every node's
+    // children nearest-to-the-camera first (rt_bvh.h: order_bvh_for_origin) whenever the camera has moved
+    rtdev::BvhBuild bvh_host;
+    double bvh_ordered_for[3] = {0, 0, 0};
+    bool bvh_is_ordered = false;
+    std::vector<rtdev::BvhNode> bvh_ordered_nodes[2]; // host copies of the array last uploaded and the one before
+    int bvh_upload_slot = 0;
 
     // pooled kernel (default): persistent grid = CUs x resident blocks of the variant
     bool use_v1 = false;   // RtSceneOptions.kernel == RT_KERNEL_V1: the lane-per-pixel kernel

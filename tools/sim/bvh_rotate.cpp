@@ -310,6 +310,67 @@ int main(int argc, char **argv) {
     }
     snprintf(line, sizeof line, "+ rotations again (%d applied)", total);
     measure(line);
+    { // (3) no new topology at all: every inner node's children in the order of their boxes' distance from the CAMERA (what
+      // a fixed-order walk wants for primary rays; indifferent to bounce rays)
+        auto dist2 = [&](const Node &nd) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) {
+                const double o = cam->origin[k], dlt = o < nd.mn[k] ? nd.mn[k] - o : (o > nd.mx[k] ? o - nd.mx[k] : 0.0);
+                s += dlt * dlt;
+            }
+            return s;
+        };
+        int swapped = 0;
+        for (Node &nd : T.n)
+            if (!nd.leaf() && dist2(T.n[nd.r]) < dist2(T.n[nd.l])) { std::swap(nd.l, nd.r); ++swapped; }
+        snprintf(line, sizeof line, "children nearest-to-camera first (%d swapped)", swapped);
+        measure(line);
+    }
+    { // (4) the PRODUCT's routine (rt_bvh.h: order_bvh_for_origin, what enqueue_render uploads for this camera): the skip-link
+      // walk over its array must find the linear scan's closest hit for every ray, and touch fewer boxes than over the
+      // builder's own order
+        auto skip_walk = [&](const std::vector<rtdev::BvhNode> &arr, const Ray &r, Count &c, int &best) {
+            double bt = INFINITY;
+            best = -1;
+            ++c.rays;
+            int i = 0;
+            while (i < n) {
+                ++c.boxes;
+                Node box;
+                for (int k = 0; k < 3; ++k) { box.mn[k] = (double)arr[(size_t)i].mn(k) + bvh.center[k]; box.mx[k] = (double)arr[(size_t)i].mx(k) + bvh.center[k]; }
+                if (hit_box(box, r, bt)) {
+                    const int fc = arr[(size_t)i].first_count;
+                    for (int k = 0; k < (fc & 7); ++k) {
+                        ++c.prims;
+                        const int pi = bvh.prim_index[(size_t)((fc >> 3) + k)];
+                        double t;
+                        if (hit_prim(d->primitives[pi], r, bt, t)) { bt = t; best = pi; }
+                    }
+                    i = i + 1;
+                } else {
+                    i = arr[(size_t)i].skip;
+                }
+            }
+            return bt;
+        };
+        const std::vector<rtdev::BvhNode> ordered = rtdev::order_bvh_for_origin(bvh, cam->origin);
+        long mismatches = 0;
+        Count c0p, c0b, c1p, c1b;
+        for (int pass = 0; pass < 2; ++pass)
+            for (const Ray &r : pass ? bounce : primary) {
+                int b0, b1, bl = -1;
+                const double t0 = skip_walk(bvh.nodes, r, pass ? c0b : c0p, b0), t1 = skip_walk(ordered, r, pass ? c1b : c1p, b1);
+                double bt = INFINITY;
+                for (int i = 0; i < d->n_primitives; ++i) {
+                    double t;
+                    if (hit_prim(d->primitives[i], r, bt, t)) { bt = t; bl = i; }
+                }
+                mismatches += !(t0 == bt && t1 == bt) || (bl >= 0 && (b0 < 0 || b1 < 0));
+            }
+        printf("order_bvh_for_origin(camera): %ld rays whose closest hit differs from the linear scan's; boxes per primary ray %.2f -> %.2f, per bounce ray %.2f -> %.2f; "
+               "leaf primitives %.2f -> %.2f, %.2f -> %.2f\n", mismatches, (double)c0p.boxes / c0p.rays, (double)c1p.boxes / c1p.rays, (double)c0b.boxes / c0b.rays,
+               (double)c1b.boxes / c1b.rays, (double)c0p.prims / c0p.rays, (double)c1p.prims / c1p.rays, (double)c0b.prims / c0b.rays, (double)c1b.prims / c1b.rays);
+    }
     rth_session_close(session);
     return 0;
 }
